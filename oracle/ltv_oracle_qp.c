@@ -1,0 +1,610 @@
+/*
+ * ltv_oracle_qp.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Restates the *contract* of the qpOASES MEX call the reference makes at
+ * mpc/ltv/kinematic/ltvmpc_kinetmatic_curvilinear.m:52 and
+ * mpc/ltv/dynamic/ltvmpc_dynamic_curvilinear.m:52 :
+ *     min 1/2 x'Hx + x'g   s.t.  lb <= x <= ub,  lbA <= A x <= ubA
+ * (optimizers/matlab/qpOASES/qpOASES.m:16-23, outputs/exit codes :41-62).
+ * qpOASES itself (coin-or/qpOASES 3.2.x, online active-set strategy) is a
+ * third-party dependency that is NOT in /root/reference (binaries only, version
+ * unpinned) => PARITY UNPINNED.  The minimiser of these convex QPs is unique in
+ * x, so any exact method must return the same x/fval; this file computes it
+ * with a dense fp64 Mehrotra predictor-corrector interior-point method followed
+ * by an active-set polish (solves the equality-constrained KKT system of the
+ * identified active set, i.e. the vertex-exact point an active-set solver
+ * stops at), and certifies it with orc_qp_kkt().
+ */
+#include "ltv_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define IDX(i, j, ld) ((size_t)(i) + (size_t)(j) * (size_t)(ld))
+
+void orc_qp_default_opts(orc_qp_opts* o) {
+  o->tol = 1e-8;
+  o->tol_x = 1e-7;
+  o->tol_loose = 1e-6;
+  o->max_iter = 100;
+  o->inf_bound = 1e9;
+  o->polish = 1;
+  o->corrector = 1;
+  o->scale = 1;
+  o->verbose = 0;
+}
+
+/* in-place Cholesky (lower) of n x n column-major; returns 0 ok, >0 index of failing pivot+1 */
+static int chol_lower(int n, double* M, double reg_floor) {
+  for (int k = 0; k < n; ++k) {
+    double p = M[IDX(k, k, n)];
+    if (!(p > reg_floor)) {
+      if (!isfinite(p)) return k + 1;
+      p = reg_floor > 0 ? reg_floor : 1e-300;
+    }
+    p = sqrt(p);
+    M[IDX(k, k, n)] = p;
+    for (int i = k + 1; i < n; ++i) M[IDX(i, k, n)] /= p;
+    for (int j = k + 1; j < n; ++j) {
+      double ljk = M[IDX(j, k, n)];
+      if (ljk == 0) continue;
+      for (int i = j; i < n; ++i) M[IDX(i, j, n)] -= M[IDX(i, k, n)] * ljk;
+    }
+  }
+  return 0;
+}
+static void chol_solve(int n, const double* L, double* b) {
+  for (int i = 0; i < n; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= L[IDX(i, k, n)] * b[k];
+    b[i] = s / L[IDX(i, i, n)];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < n; ++k) s -= L[IDX(k, i, n)] * b[k];
+    b[i] = s / L[IDX(i, i, n)];
+  }
+}
+
+/* dense LU with partial pivoting, solves K y = r in place; returns 0 ok, 1 singular */
+static int lu_solve(int n, double* K, double* r) {
+  for (int k = 0; k < n; ++k) {
+    int p = k; double best = fabs(K[IDX(k, k, n)]);
+    for (int i = k + 1; i < n; ++i) if (fabs(K[IDX(i, k, n)]) > best) { best = fabs(K[IDX(i, k, n)]); p = i; }
+    if (best < 1e-13) return 1;
+    if (p != k) {
+      for (int j = 0; j < n; ++j) { double t = K[IDX(k, j, n)]; K[IDX(k, j, n)] = K[IDX(p, j, n)]; K[IDX(p, j, n)] = t; }
+      double t = r[k]; r[k] = r[p]; r[p] = t;
+    }
+    double piv = K[IDX(k, k, n)];
+    for (int i = k + 1; i < n; ++i) {
+      double f = K[IDX(i, k, n)] / piv;
+      if (f == 0) continue;
+      K[IDX(i, k, n)] = f;
+      for (int j = k + 1; j < n; ++j) K[IDX(i, j, n)] -= f * K[IDX(k, j, n)];
+      r[i] -= f * r[k];
+    }
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = r[i];
+    for (int j = i + 1; j < n; ++j) s -= K[IDX(i, j, n)] * r[j];
+    r[i] = s / K[IDX(i, i, n)];
+  }
+  return 0;
+}
+
+double orc_qp_kkt(int nV, int nC, const double* H, const double* g, const double* A,
+                  const double* lb, const double* ub, const double* lbA, const double* ubA,
+                  const double* x, const double* lambda, double inf_bound, double* res) {
+  int n = nV, m = nC;
+  double r_stat = 0, r_prim = 0, r_sign = 0, r_comp = 0;
+  double fval = 0;
+  double* Hx = (double*)calloc(n, sizeof(double));
+  double* Gz = (double*)calloc(n, sizeof(double));
+  for (int j = 0; j < n; ++j)
+    for (int i = 0; i < n; ++i) Hx[i] += H[IDX(i, j, n)] * x[j];
+  for (int i = 0; i < n; ++i) fval += 0.5 * x[i] * Hx[i] + g[i] * x[i];
+  double fs = fmax(1.0, fabs(fval));
+  for (int i = 0; i < n; ++i) Gz[i] = lambda[i];
+  for (int r = 0; r < m; ++r) {
+    double lam = lambda[n + r];
+    if (lam != 0) for (int j = 0; j < n; ++j) Gz[j] += A[IDX(r, j, m)] * lam;
+  }
+  for (int j = 0; j < n; ++j) {
+    double sc = fmax(1.0, fmax(fabs(g[j]), fmax(fabs(Hx[j]), fabs(Gz[j]))));
+    r_stat = fmax(r_stat, fabs(Hx[j] + g[j] - Gz[j]) / sc);
+  }
+  for (int i = 0; i < n + m; ++i) {
+    double v, l, u;
+    if (i < n) { v = x[i]; l = lb[i]; u = ub[i]; }
+    else {
+      int r = i - n; v = 0;
+      for (int j = 0; j < n; ++j) v += A[IDX(r, j, m)] * x[j];
+      l = lbA[r]; u = ubA[r];
+    }
+    int hl = l > -inf_bound, hu = u < inf_bound;
+    double sc = fmax(1.0, fabs(v));
+    if (hl) { sc = fmax(sc, fabs(l)); }
+    if (hu) { sc = fmax(sc, fabs(u)); }
+    double viol = 0;
+    if (l > -INFINITY && v < l) viol = l - v;
+    if (u < INFINITY && v > u) viol = fmax(viol, v - u);
+    r_prim = fmax(r_prim, viol / sc);
+    double lam = lambda[i];
+    if (lam > 0) {
+      if (!hl) r_sign = fmax(r_sign, lam / fs);
+      else r_comp = fmax(r_comp, lam * fabs(v - l) / fs);
+    } else if (lam < 0) {
+      if (!hu) r_sign = fmax(r_sign, -lam / fs);
+      else r_comp = fmax(r_comp, -lam * fabs(u - v) / fs);
+    }
+  }
+  free(Hx); free(Gz);
+  if (res) { res[0] = r_stat; res[1] = r_prim; res[2] = r_sign; res[3] = r_comp; }
+  return fmax(fmax(r_stat, r_prim), fmax(r_sign, r_comp));
+}
+
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  int n, m, mt;
+  double *H, *g, *A;      /* scaled copies */
+  double *l, *u;          /* mt, scaled */
+  unsigned char *hl, *hu; /* mt */
+  double *E, *F;          /* column / row scaling */
+} qp_work;
+
+static void apply_G(const qp_work* w, const double* x, double* v) { /* v = [x; A x] */
+  int n = w->n, m = w->m;
+  for (int i = 0; i < n; ++i) v[i] = x[i];
+  for (int r = 0; r < m; ++r) v[n + r] = 0;
+  for (int j = 0; j < n; ++j) {
+    double xj = x[j];
+    if (xj == 0) continue;
+    const double* col = w->A + (size_t)j * m;
+    for (int r = 0; r < m; ++r) v[n + r] += col[r] * xj;
+  }
+}
+static void apply_Gt(const qp_work* w, const double* y, double* out) { /* out = y[0:n] + A' y[n:] */
+  int n = w->n, m = w->m;
+  for (int j = 0; j < n; ++j) {
+    const double* col = w->A + (size_t)j * m;
+    double s = y[j];
+    for (int r = 0; r < m; ++r) s += col[r] * y[n + r];
+    out[j] = s;
+  }
+}
+
+static int polish(int n, int m, const double* H, const double* g, const double* A,
+                  const double* lb, const double* ub, const double* lbA, const double* ubA,
+                  double inf_bound, double* x, double* lambda) {
+  /* active set guess from the interior-point multipliers: side active iff |lambda| dominates its slack */
+  int mt = n + m, na = 0;
+  int* act = (int*)malloc(sizeof(int) * mt);
+  double* rhs_a = (double*)malloc(sizeof(double) * mt);
+  double* v = (double*)calloc(mt, sizeof(double));
+  for (int i = 0; i < n; ++i) v[i] = x[i];
+  for (int j = 0; j < n; ++j) for (int r = 0; r < m; ++r) v[n + r] += A[IDX(r, j, m)] * x[j];
+  for (int i = 0; i < mt; ++i) {
+    double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
+    double lam = lambda[i];
+    if (lam > 0 && l > -inf_bound && lam > fabs(v[i] - l)) { act[na] = i; rhs_a[na] = l; ++na; }
+    else if (lam < 0 && u < inf_bound && -lam > fabs(u - v[i])) { act[na] = i; rhs_a[na] = u; ++na; }
+  }
+  int ok = 0;
+  if (na <= n) {
+    int K = n + na;
+    double* KK = (double*)calloc((size_t)K * K, sizeof(double));
+    double* r = (double*)calloc(K, sizeof(double));
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) KK[IDX(i, j, K)] = H[IDX(i, j, n)];
+    for (int a = 0; a < na; ++a) {
+      int i = act[a];
+      for (int j = 0; j < n; ++j) {
+        double gij = i < n ? (i == j ? 1.0 : 0.0) : A[IDX(i - n, j, m)];
+        KK[IDX(n + a, j, K)] = gij;
+        KK[IDX(j, n + a, K)] = -gij; /* H x - G_a' lam = -g */
+      }
+      r[n + a] = rhs_a[a];
+    }
+    for (int j = 0; j < n; ++j) r[j] = -g[j];
+    if (lu_solve(K, KK, r) == 0) {
+      /* accept only if still primal feasible and duals keep their sign (to tight tolerance) */
+      double* v2 = (double*)calloc(mt, sizeof(double));
+      for (int i = 0; i < n; ++i) v2[i] = r[i];
+      for (int j = 0; j < n; ++j) for (int rr = 0; rr < m; ++rr) v2[n + rr] += A[IDX(rr, j, m)] * r[j];
+      int good = 1;
+      double dxmax = 0, xmax = 1;
+      for (int i = 0; i < n; ++i) { dxmax = fmax(dxmax, fabs(r[i] - x[i])); xmax = fmax(xmax, fabs(x[i])); }
+      (void)dxmax; (void)xmax; /* acceptance is by KKT alone: feasibility + multiplier signs certify optimality */
+      for (int i = 0; i < mt && good; ++i) {
+        double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
+        double sc = fmax(1.0, fabs(v2[i]));
+        if (l > -INFINITY && v2[i] < l - 1e-9 * fmax(sc, fabs(l))) good = 0;
+        if (u < INFINITY && v2[i] > u + 1e-9 * fmax(sc, fabs(u))) good = 0;
+      }
+      for (int a = 0; a < na && good; ++a) {
+        double lam_new = r[n + a], lam_old = lambda[act[a]];
+        if (lam_new * lam_old < 0 && fabs(lam_new) > 1e-9 * fmax(1.0, fabs(lam_old))) good = 0;
+      }
+      if (good) {
+        for (int i = 0; i < n; ++i) x[i] = r[i];
+        for (int i = 0; i < mt; ++i) lambda[i] = 0;
+        for (int a = 0; a < na; ++a) lambda[act[a]] = r[n + a];
+        ok = 1;
+      }
+      free(v2);
+    }
+    free(KK); free(r);
+  }
+  free(act); free(rhs_a); free(v);
+  return ok;
+}
+
+int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double* A,
+                 const double* lb, const double* ub, const double* lbA, const double* ubA,
+                 const orc_qp_opts* opts_in, double* x_out, double* fval_out, int* iter_out, double* lambda_out) {
+  orc_qp_opts opts;
+  if (opts_in) opts = *opts_in; else orc_qp_default_opts(&opts);
+  const int n = nV, m = nC, mt = n + m;
+  int flag = 1, it = 0;
+  qp_work w;
+  w.n = n; w.m = m; w.mt = mt;
+  w.H = (double*)malloc(sizeof(double) * n * n);
+  w.g = (double*)malloc(sizeof(double) * n);
+  w.A = (double*)malloc(sizeof(double) * (size_t)(m > 0 ? m : 1) * n);
+  w.l = (double*)malloc(sizeof(double) * mt);
+  w.u = (double*)malloc(sizeof(double) * mt);
+  w.hl = (unsigned char*)malloc(mt);
+  w.hu = (unsigned char*)malloc(mt);
+  w.E = (double*)malloc(sizeof(double) * n);
+  w.F = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+  double *x = (double*)calloc(n, sizeof(double)), *dx = (double*)calloc(n, sizeof(double)),
+         *dxa = (double*)calloc(n, sizeof(double));
+  double *tl = (double*)calloc(mt, sizeof(double)), *tu = (double*)calloc(mt, sizeof(double)),
+         *zl = (double*)calloc(mt, sizeof(double)), *zu = (double*)calloc(mt, sizeof(double));
+  double *v = (double*)calloc(mt, sizeof(double)), *dv = (double*)calloc(mt, sizeof(double)),
+         *wv = (double*)calloc(mt, sizeof(double)), *D = (double*)calloc(mt, sizeof(double));
+  double *rpl = (double*)calloc(mt, sizeof(double)), *rpu = (double*)calloc(mt, sizeof(double));
+  double *dtl = (double*)calloc(mt, sizeof(double)), *dtu = (double*)calloc(mt, sizeof(double)),
+         *dzl = (double*)calloc(mt, sizeof(double)), *dzu = (double*)calloc(mt, sizeof(double));
+  double *cl = (double*)calloc(mt, sizeof(double)), *cu = (double*)calloc(mt, sizeof(double));
+  double *Hx = (double*)calloc(n, sizeof(double)), *Gz = (double*)calloc(n, sizeof(double)),
+         *rhs = (double*)calloc(n, sizeof(double)), *tmp = (double*)calloc(n, sizeof(double));
+  double* M = (double*)malloc(sizeof(double) * n * n);
+  int have_saved = 0;
+  double saved_merit = INFINITY;
+  double* xs = (double*)calloc(n, sizeof(double));
+  double* lams = (double*)calloc(mt, sizeof(double));
+
+  /* ---- scaling: x = E xs ; rows of A scaled by F --------------------------- */
+  for (int j = 0; j < n; ++j) {
+    double e = 1.0;
+    if (opts.scale) {
+      double hjj = H[IDX(j, j, n)];
+      if (hjj > 1e-12) e = 1.0 / sqrt(hjj);
+      else {
+        double cm = 0;
+        for (int r = 0; r < m; ++r) cm = fmax(cm, fabs(A[IDX(r, j, m)]));
+        e = cm > 1e-12 ? 1.0 / cm : 1.0;
+      }
+    }
+    w.E[j] = e;
+  }
+  for (int r = 0; r < m; ++r) {
+    double f = 1.0;
+    if (opts.scale) {
+      double rm = 0;
+      for (int j = 0; j < n; ++j) rm = fmax(rm, fabs(A[IDX(r, j, m)] * w.E[j]));
+      f = rm > 1e-12 ? 1.0 / rm : 1.0;
+    }
+    w.F[r] = f;
+  }
+  for (int j = 0; j < n; ++j) {
+    for (int i = 0; i < n; ++i) w.H[IDX(i, j, n)] = H[IDX(i, j, n)] * w.E[i] * w.E[j];
+    w.g[j] = g[j] * w.E[j];
+    for (int r = 0; r < m; ++r) w.A[IDX(r, j, m)] = A[IDX(r, j, m)] * w.F[r] * w.E[j];
+  }
+  int infeasible_bounds = 0, cnt = 0;
+  for (int i = 0; i < mt; ++i) {
+    double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
+    double sc = i < n ? 1.0 / w.E[i] : w.F[i - n];
+    if (isnan(l) || isnan(u)) { infeasible_bounds = 2; }
+    w.hl[i] = l > -opts.inf_bound; w.hu[i] = u < opts.inf_bound;
+    w.l[i] = w.hl[i] ? l * sc : -INFINITY;
+    w.u[i] = w.hu[i] ? u * sc : INFINITY;
+    if (w.hl[i] && w.hu[i] && l > u) infeasible_bounds = 1;
+    if (w.hl[i] && w.hu[i] && !(u > l)) {
+      /* equality row: open a tiny interior so the barrier is defined (documented relaxation) */
+      double eps = 1e-9 * fmax(1.0, fabs(w.l[i]));
+      w.l[i] -= eps; w.u[i] += eps;
+    }
+    cnt += w.hl[i] + w.hu[i];
+  }
+  if (infeasible_bounds) { flag = infeasible_bounds == 1 ? -2 : -1; goto finish; }
+
+  /* ---- initial point --------------------------------------------------------- */
+  for (int j = 0; j < n; ++j) {
+    double xj = 0;
+    if (w.hl[j] && xj < w.l[j]) xj = w.l[j];
+    if (w.hu[j] && xj > w.u[j]) xj = w.u[j];
+    x[j] = xj;
+  }
+  apply_G(&w, x, v);
+  for (int i = 0; i < mt; ++i) {
+    if (w.hl[i]) { tl[i] = fmax(v[i] - w.l[i], 1.0); zl[i] = 1.0; }
+    if (w.hu[i]) { tu[i] = fmax(w.u[i] - v[i], 1.0); zu[i] = 1.0; }
+  }
+  /* bound multipliers absorb the initial dual residual (keeps the first Newton step sane when
+   * |g| is huge, e.g. the 1e8 slack cost of ltvmpc_*.m:35) */
+  for (int i = 0; i < mt; ++i) wv[i] = i < n ? 0.0 : (w.hl[i] ? zl[i] : 0) - (w.hu[i] ? zu[i] : 0);
+  apply_Gt(&w, wv, Gz);
+  for (int j = 0; j < n; ++j) {
+    double hx = 0;
+    for (int i = 0; i < n; ++i) hx += w.H[IDX(j, i, n)] * x[i];
+    double r = hx + w.g[j] - Gz[j];
+    if (w.hl[j]) zl[j] = fmax(r, 0.0) + 1.0;
+    if (w.hu[j]) zu[j] = fmax(-r, 0.0) + 1.0;
+  }
+
+  double best_res = INFINITY;
+  int stall = 0;
+  for (it = 0; it <= opts.max_iter; ++it) {
+    /* residuals */
+    apply_G(&w, x, v);
+    double mu = 0;
+    for (int i = 0; i < mt; ++i) {
+      rpl[i] = w.hl[i] ? v[i] - w.l[i] - tl[i] : 0;
+      rpu[i] = w.hu[i] ? w.u[i] - v[i] - tu[i] : 0;
+      wv[i] = (w.hl[i] ? zl[i] : 0) - (w.hu[i] ? zu[i] : 0);
+      mu += (w.hl[i] ? tl[i] * zl[i] : 0) + (w.hu[i] ? tu[i] * zu[i] : 0);
+    }
+    double gap = mu;
+    mu = cnt > 0 ? mu / cnt : 0;
+    apply_Gt(&w, wv, Gz);
+    double fval = 0;
+    for (int i = 0; i < n; ++i) Hx[i] = 0;
+    for (int j = 0; j < n; ++j) { double xj = x[j]; for (int i = 0; i < n; ++i) Hx[i] += w.H[IDX(i, j, n)] * xj; }
+    for (int i = 0; i < n; ++i) fval += 0.5 * x[i] * Hx[i] + w.g[i] * x[i];
+    double rd_rel = 0, rp_rel = 0;
+    for (int j = 0; j < n; ++j) {
+      double sc = fmax(1.0, fmax(fabs(w.g[j]), fmax(fabs(Hx[j]), fabs(Gz[j]))));
+      rd_rel = fmax(rd_rel, fabs(Hx[j] + w.g[j] - Gz[j]) / sc);
+    }
+    for (int i = 0; i < mt; ++i) {
+      double sc = fmax(1.0, fabs(v[i]));
+      if (w.hl[i]) rp_rel = fmax(rp_rel, fabs(rpl[i]) / fmax(sc, fabs(w.l[i])));
+      if (w.hu[i]) rp_rel = fmax(rp_rel, fabs(rpu[i]) / fmax(sc, fabs(w.u[i])));
+    }
+    double gap_rel = gap / fmax(1.0, fabs(fval));
+    if (opts.verbose) printf("it %2d mu %.3e rd %.3e rp %.3e gap %.3e f %.8e\n", it, mu, rd_rel, rp_rel, gap_rel, fval);
+    /* two levels: `tol` (strict, default 1e-8) ends the iteration together with the Newton-decrement test;
+     * `tol_loose` (default 1e-6 = the KKT tolerance the build is specified to) qualifies an iterate as a
+     * fall-back: the normal matrix loses all accuracy once the weights z/t pass ~1e19 (1e8 slack cost), and
+     * the best qualified iterate is returned when the next steps turn to numerical garbage */
+    const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
+    const int res_ok = merit <= opts.tol;
+    if (merit <= opts.tol_loose && merit < saved_merit) {
+      for (int j = 0; j < n; ++j) xs[j] = x[j];
+      for (int i = 0; i < mt; ++i) lams[i] = (w.hl[i] ? zl[i] : 0) - (w.hu[i] ? zu[i] : 0);
+      have_saved = 1; saved_merit = merit;
+    } else if (have_saved && merit > opts.tol_loose) {
+      flag = 2; break;
+    }
+    double res_now = fmax(rd_rel, fmax(rp_rel, gap_rel));
+    if (!isfinite(res_now)) { if (opts.verbose) printf("nonfinite residual\n"); flag = -1; break; }
+    if (res_now < 0.9 * best_res) { best_res = res_now; stall = 0; } else ++stall;
+
+    /* normal matrix M = H + diag(D_b) + A' D_A A */
+    for (int i = 0; i < mt; ++i) D[i] = (w.hl[i] ? zl[i] / tl[i] : 0) + (w.hu[i] ? zu[i] / tu[i] : 0);
+    memcpy(M, w.H, sizeof(double) * n * n);
+    for (int j = 0; j < n; ++j) M[IDX(j, j, n)] += D[j];
+    for (int j = 0; j < n; ++j) {
+      const double* cj = w.A + (size_t)j * m;
+      for (int i = j; i < n; ++i) {
+        const double* ci = w.A + (size_t)i * m;
+        double s = 0;
+        for (int r = 0; r < m; ++r) s += ci[r] * D[n + r] * cj[r];
+        M[IDX(i, j, n)] += s;
+      }
+    }
+    double dmax = 0;
+    for (int j = 0; j < n; ++j) dmax = fmax(dmax, M[IDX(j, j, n)]);
+    { int ce = chol_lower(n, M, 1e-30 * dmax); if (ce) { if (opts.verbose) printf("chol fail at %d dmax %g\n", ce, dmax); flag = res_ok ? 0 : (have_saved ? 2 : -1); break; } }
+
+    /* predictor */
+    for (int i = 0; i < mt; ++i)
+      wv[i] = (w.hl[i] ? -(zl[i] / tl[i]) * rpl[i] : 0) + (w.hu[i] ? (zu[i] / tu[i]) * rpu[i] : 0);
+    apply_Gt(&w, wv, tmp);
+    for (int j = 0; j < n; ++j) { rhs[j] = -(Hx[j] + w.g[j]) + tmp[j]; dxa[j] = rhs[j]; }
+    chol_solve(n, M, dxa);
+    /* Newton-decrement test: the affine direction is the predicted remaining move to the KKT point;
+     * stop when it is below tol_x in the caller's (unscaled) coordinates. |f| can be ~1e9 because of
+     * the 1e8 slack cost, so a gap test relative to |f| alone leaves x loose in flat directions. */
+    if (res_ok) {
+      double dmx = 0, xmx = 1.0;
+      for (int j = 0; j < n; ++j) { dmx = fmax(dmx, fabs(dxa[j] * w.E[j])); xmx = fmax(xmx, fabs(x[j] * w.E[j])); }
+      if (opts.verbose) printf("      dxaff_rel %.3e\n", dmx / xmx);
+      if (dmx <= opts.tol_x * xmx) { flag = 0; break; }
+    }
+    if (it == opts.max_iter) { flag = 1; break; }
+    apply_G(&w, dxa, dv);
+    double alpha_aff = 1.0;
+    for (int i = 0; i < mt; ++i) {
+      if (w.hl[i]) {
+        dtl[i] = dv[i] + rpl[i];
+        dzl[i] = -zl[i] - (zl[i] / tl[i]) * dtl[i];
+        if (dtl[i] < 0) alpha_aff = fmin(alpha_aff, -tl[i] / dtl[i]);
+        if (dzl[i] < 0) alpha_aff = fmin(alpha_aff, -zl[i] / dzl[i]);
+      }
+      if (w.hu[i]) {
+        dtu[i] = -dv[i] + rpu[i];
+        dzu[i] = -zu[i] - (zu[i] / tu[i]) * dtu[i];
+        if (dtu[i] < 0) alpha_aff = fmin(alpha_aff, -tu[i] / dtu[i]);
+        if (dzu[i] < 0) alpha_aff = fmin(alpha_aff, -zu[i] / dzu[i]);
+      }
+    }
+    double mu_aff = 0;
+    for (int i = 0; i < mt; ++i) {
+      if (w.hl[i]) mu_aff += (tl[i] + alpha_aff * dtl[i]) * (zl[i] + alpha_aff * dzl[i]);
+      if (w.hu[i]) mu_aff += (tu[i] + alpha_aff * dtu[i]) * (zu[i] + alpha_aff * dzu[i]);
+    }
+    mu_aff = cnt > 0 ? mu_aff / cnt : 0;
+    double sigma = mu > 0 ? pow(mu_aff / mu, 3.0) : 0;
+    if (sigma > 1) sigma = 1;
+    {
+      /* do not drive mu far below what the gap criterion needs (keeps M well conditioned) */
+      double mu_floor = 1e-5 * opts.tol * fmax(1.0, fabs(fval)) / (cnt > 0 ? cnt : 1);
+      if (mu > 0 && sigma < mu_floor / mu) sigma = fmin(1.0, mu_floor / mu);
+    }
+    /* corrector */
+    for (int i = 0; i < mt; ++i) {
+      cl[i] = w.hl[i] ? sigma * mu - (opts.corrector ? dtl[i] * dzl[i] : 0) : 0;
+      cu[i] = w.hu[i] ? sigma * mu - (opts.corrector ? dtu[i] * dzu[i] : 0) : 0;
+      wv[i] = (w.hl[i] ? cl[i] / tl[i] : 0) - (w.hu[i] ? cu[i] / tu[i] : 0);
+    }
+    apply_Gt(&w, wv, tmp);
+    for (int j = 0; j < n; ++j) dx[j] = rhs[j] + tmp[j];
+    chol_solve(n, M, dx);
+    apply_G(&w, dx, dv);
+    /* step length: Mehrotra's heuristic on the blocking pair (as in OOQP): keeps the pair that blocks
+     * the step from collapsing far below the average complementarity, which otherwise jams the method */
+    double alpha = 1e300, bp = 0, bdp = 0, bd = 0, bdd = 0;
+    for (int i = 0; i < mt; ++i) {
+      if (w.hl[i]) {
+        dtl[i] = dv[i] + rpl[i];
+        dzl[i] = -zl[i] + cl[i] / tl[i] - (zl[i] / tl[i]) * dtl[i];
+        if (dtl[i] < 0 && -tl[i] / dtl[i] < alpha) { alpha = -tl[i] / dtl[i]; bp = tl[i]; bdp = dtl[i]; bd = zl[i]; bdd = dzl[i]; }
+        if (dzl[i] < 0 && -zl[i] / dzl[i] < alpha) { alpha = -zl[i] / dzl[i]; bp = zl[i]; bdp = dzl[i]; bd = tl[i]; bdd = dtl[i]; }
+      }
+      if (w.hu[i]) {
+        dtu[i] = -dv[i] + rpu[i];
+        dzu[i] = -zu[i] + cu[i] / tu[i] - (zu[i] / tu[i]) * dtu[i];
+        if (dtu[i] < 0 && -tu[i] / dtu[i] < alpha) { alpha = -tu[i] / dtu[i]; bp = tu[i]; bdp = dtu[i]; bd = zu[i]; bdd = dzu[i]; }
+        if (dzu[i] < 0 && -zu[i] / dzu[i] < alpha) { alpha = -zu[i] / dzu[i]; bp = zu[i]; bdp = dzu[i]; bd = tu[i]; bdd = dtu[i]; }
+      }
+    }
+    if (alpha < 1e299) {
+      const double gamma_f = 0.99, gamma_a = 1.0 / (1.0 - gamma_f);
+      double mufull = 0;
+      for (int i = 0; i < mt; ++i) {
+        if (w.hl[i]) mufull += (tl[i] + alpha * dtl[i]) * (zl[i] + alpha * dzl[i]);
+        if (w.hu[i]) mufull += (tu[i] + alpha * dtu[i]) * (zu[i] + alpha * dzu[i]);
+      }
+      mufull = mufull / cnt / gamma_a;
+      double a_h = (-bp + mufull / (bd + alpha * bdd)) / bdp;
+      alpha = fmin(1.0, fmin(0.99999999 * alpha, fmax(a_h, gamma_f * alpha))); /* stay strictly interior */
+    } else alpha = 1.0;
+    if (opts.verbose) { double sm = 0, xm = 1; for (int j = 0; j < n; ++j) { sm = fmax(sm, fabs(alpha * dx[j] * w.E[j])); xm = fmax(xm, fabs(x[j] * w.E[j])); } printf("      alpha_aff %.3e sigma %.3e alpha %.4f step_rel %.3e\n", alpha_aff, sigma, alpha, sm / xm); }
+    for (int j = 0; j < n; ++j) x[j] += alpha * dx[j];
+    for (int i = 0; i < mt; ++i) {
+      if (w.hl[i]) { tl[i] += alpha * dtl[i]; zl[i] += alpha * dzl[i]; }
+      if (w.hu[i]) { tu[i] += alpha * dtu[i]; zu[i] += alpha * dzu[i]; }
+    }
+    /* divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47) */
+    double xn = 0, zn = 0;
+    for (int j = 0; j < n; ++j) xn = fmax(xn, fabs(x[j]));
+    for (int i = 0; i < mt; ++i) zn = fmax(zn, fmax(w.hl[i] ? zl[i] : 0, w.hu[i] ? zu[i] : 0));
+    if (xn > 1e13) { flag = -3; break; }
+    if (zn > 1e15 && rp_rel > 1e-6) { flag = -2; break; }
+    if (stall > 25) { flag = rp_rel > 1e-6 ? -2 : 1; break; }
+  }
+
+finish:
+  if (flag == 2 || ((flag == 1 || flag == -1) && have_saved)) {
+    /* fall back to the last iterate that met the residual tolerances */
+    for (int j = 0; j < n; ++j) x[j] = xs[j];
+    for (int i = 0; i < mt; ++i) { zl[i] = lams[i] > 0 ? lams[i] : 0; zu[i] = lams[i] < 0 ? -lams[i] : 0; }
+    flag = 0;
+  }
+  /* unscale */
+  if (flag == 0 || flag == 1) {
+    for (int j = 0; j < n; ++j) x_out[j] = x[j] * w.E[j];
+    if (lambda_out) {
+      for (int j = 0; j < n; ++j) lambda_out[j] = ((w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0)) / w.E[j];
+      for (int r = 0; r < m; ++r) lambda_out[n + r] = ((w.hl[n + r] ? zl[n + r] : 0) - (w.hu[n + r] ? zu[n + r] : 0)) * w.F[r];
+    }
+    if (flag == 0 && opts.polish) {
+      double* lam = lambda_out;
+      if (!lam) {
+        lam = (double*)malloc(sizeof(double) * mt);
+        for (int j = 0; j < n; ++j) lam[j] = ((w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0)) / w.E[j];
+        for (int r = 0; r < m; ++r) lam[n + r] = ((w.hl[n + r] ? zl[n + r] : 0) - (w.hu[n + r] ? zu[n + r] : 0)) * w.F[r];
+      }
+      polish(n, m, H, g, A, lb, ub, lbA, ubA, opts.inf_bound, x_out, lam);
+      if (!lambda_out) free(lam);
+    }
+  } else {
+    for (int j = 0; j < n; ++j) x_out[j] = NAN;
+    if (lambda_out) for (int i = 0; i < mt; ++i) lambda_out[i] = NAN;
+  }
+  if (fval_out) {
+    double f = 0;
+    for (int j = 0; j < n; ++j) {
+      double s = 0;
+      for (int i = 0; i < n; ++i) s += H[IDX(i, j, n)] * x_out[i];
+      f += 0.5 * s * x_out[j] + g[j] * x_out[j];
+    }
+    *fval_out = f;
+  }
+  if (iter_out) *iter_out = it;
+  free(w.H); free(w.g); free(w.A); free(w.l); free(w.u); free(w.hl); free(w.hu); free(w.E); free(w.F);
+  free(x); free(dx); free(dxa); free(tl); free(tu); free(zl); free(zu); free(v); free(dv); free(wv); free(D);
+  free(rpl); free(rpu); free(dtl); free(dtu); free(dzl); free(dzu); free(cl); free(cu);
+  free(Hx); free(Gz); free(rhs); free(tmp); free(M); free(xs); free(lams);
+  return flag;
+}
+
+int orc_ltv_step(int model, int N, double dt, const orc_spline* sp,
+                 const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                 const orc_qp_opts* opts, double* u_opt, double* x_opt, double* slack, double* fval, int* iter) {
+  const int nx = orc_nx(model), ns = orc_ns(model), nV = orc_nV(model, N), nC = orc_nC(model, N), R = nx * N;
+  double* H = (double*)malloc(sizeof(double) * nV * nV);
+  double* g = (double*)malloc(sizeof(double) * nV);
+  double* A = (double*)malloc(sizeof(double) * (size_t)nC * nV);
+  double* lb = (double*)malloc(sizeof(double) * nV), *ub = (double*)malloc(sizeof(double) * nV);
+  double* lbA = (double*)malloc(sizeof(double) * nC), *ubA = (double*)malloc(sizeof(double) * nC);
+  double* A_bar = (double*)malloc(sizeof(double) * R * nx);
+  double* Bt = (double*)malloc(sizeof(double) * (size_t)R * nV);
+  double* d_bar = (double*)malloc(sizeof(double) * R);
+  double* z = (double*)malloc(sizeof(double) * nV);
+  double qc, fv;
+  orc_ltv_build_qp(model, -1, N, dt, sp, x0, x_ref, x_lin, u_lin, H, g, A, lb, ub, lbA, ubA, A_bar, Bt, d_bar, &qc);
+  int flag = orc_qp_solve(nV, nC, H, g, A, lb, ub, lbA, ubA, opts, z, &fv, iter, 0); /* ltvmpc_*.m:52 */
+  /* ltvmpc_*.m:57-60 */
+  for (int s = 0; s < ns; ++s) slack[s] = z[2 * N + s];
+  for (int r = 0; r < R; ++r) {
+    double s = d_bar[r];
+    for (int c = 0; c < nx; ++c) s += A_bar[IDX(r, c, R)] * x0[c];
+    for (int c = 0; c < nV; ++c) s += Bt[IDX(r, c, R)] * z[c];
+    x_opt[r] = s;
+  }
+  for (int c = 0; c < 2 * N; ++c) u_opt[c] = z[c];
+  *fval = fv + qc;
+  free(H); free(g); free(A); free(lb); free(ub); free(lbA); free(ubA); free(A_bar); free(Bt); free(d_bar); free(z);
+  return flag;
+}
+
+int orc_qp_solve_batch(int nV, int nC, int batch, const double* H, const double* g, const double* A,
+                       const double* lb, const double* ub, const double* lbA, const double* ubA,
+                       const orc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
+                       double* lambda, int threads) {
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+  used = omp_get_max_threads();
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int b = 0; b < batch; ++b) {
+    int it = 0; double fv = 0;
+    int fl = orc_qp_solve(nV, nC, H + (size_t)b * nV * nV, g + (size_t)b * nV, A + (size_t)b * nC * nV,
+                          lb + (size_t)b * nV, ub + (size_t)b * nV, lbA + (size_t)b * nC, ubA + (size_t)b * nC, opts,
+                          x + (size_t)b * nV, &fv, &it, lambda ? lambda + (size_t)b * (nV + nC) : 0);
+    if (fval) fval[b] = fv;
+    if (exitflag) exitflag[b] = fl;
+    if (iter) iter[b] = it;
+  }
+  return used;
+}
