@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- QP solves/sec of the batched LTV-MPC QP hot path on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): batch of 4096 independent condensed QPs per GPU, curvilinear kinematic
+bicycle, N=40 (nV=81, nC=240), fp64, generic mode of SURVEY 8(d): the dense (H,g,A,lb,ub,lbA,ubA) tensors are
+resident in HBM when the timed region starts; one step = one batched solve (+ the RCCL gather of x when N>1).
+  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+Rank 0 prints ONE JSON line.  cpu_baseline = the CPU oracle timed on the host cores (a reported baseline)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (the microarch guide lists no fp64 row)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU (weak scaling)")
+    ap.add_argument("--horizon", type=int, default=40)
+    ap.add_argument("--model", default="kinematic", choices=["kinematic", "dynamic"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import fsae_mpc_amd as fm
+    from fsae_mpc_amd import shard
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    model = fm.KINEMATIC if args.model == "kinematic" else fm.DYNAMIC
+    N, dt, Bl = args.horizon, 0.05, args.batch
+    Btot = Bl * world
+    nx, ns, nV, nC = fm.dims(model, N)
+    tr = fm.Track.load("fsg2019")
+    lo, hi = rank * Bl, (rank + 1) * Bl                      # index-pure shard of the global instance ids
+    x0, xl, ul, xr = fm.instances(model, N, dt, tr.L, 20190, np.arange(lo, hi))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    stepper = fm.LtvBatch(model, N, dt, tr, Bl, device=dev)
+    q = stepper.build_qp(up(x0), up(xr), up(xl), up(ul))      # product construction kernels (untimed setup)
+    torch.cuda.synchronize(dev)
+    qp_args = [q[k] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")]
+    ws = None
+    L = fm.lib()
+
+    def step():
+        nonlocal ws
+        out = fm.qp_solve_batch_device(*qp_args, workspace=ws)
+        ws = out["workspace"]
+        if world > 1:
+            out["x_all"] = shard.gather_rows(out["x"], Btot, rank, world)   # the only exchange: final gather over RCCL/xGMI
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    L.fsaempc_qp_set_timing(1)
+    solve_ms, prep_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        a, b = C.c_double(0), C.c_double(0)
+        L.fsaempc_qp_get_timing(C.byref(a), C.byref(b))       # HIP events on the launch stream; syncs this step
+        prep_ms.append(a.value); solve_ms.append(b.value)
+    barrier()
+    t_local = time.perf_counter() - t0
+    L.fsaempc_qp_set_timing(0)
+    t_job = shard.max_over_ranks(t_local, device=dev)         # MAX over ranks
+
+    flags = out["exitflag"].cpu().numpy()
+    iters = out["iter"].cpu().numpy()
+    solved = int((flags == 0).sum())
+    n_ok = shard.max_over_ranks(float(-solved), device=dev)   # min over ranks via max of negatives
+    mean_it = float(iters.mean())
+    value = Btot * args.steps / t_job
+    flops_iter = 2.0 * nC * nV * nV + nV ** 3 / 3.0 + 4.0 * nC * nV + 2.0 * nV * nV
+    flops_launch = flops_iter * mean_it * Bl
+    k_ms = float(np.mean(solve_ms))
+    achieved = flops_launch / (k_ms * 1e-3) / 1e12
+    bytes_solve = 8.0 * (nV * nV + nV + nC * nV + 2 * nV + 2 * nC) + 8.0 * (nV + 2)
+
+    res = {
+        "metric": "QP solves/sec (batched LTV-MPC, N=%d nx=%d nu=2 fp64)" % (N, nx),
+        "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * t_job / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batch=%d independent condensed QPs per GPU, %s model, N=%d, nV=%d, nC=%d, generic mode (dense H,g,A,bounds resident in HBM)"
+                               % (Bl, args.model, N, nV, nC),
+                   "batch_per_gpu": Bl, "global_batch": Btot, "track": "fsg2019", "seed": 20190,
+                   "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "tol_kkt": 1e-8,
+                   "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,
+                   "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
+        "roofline": {"bound": "mfma", "kernel": "qp_solve_kernel<%d>" % ((nV + 15) // 16), "achieved": achieved,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "flops_per_launch": flops_launch, "algorithmic_bytes_per_solve": bytes_solve,
+                     "hbm_frac_one_pass": bytes_solve * Bl / (k_ms * 1e-3) / 8e12},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle as orc
+        otr = orc.Track.load(os.path.join(ROOT, "fsae-mpc_amd", "tracks", "fsg2019.json"))
+        cores = os.cpu_count() or 1
+        H, g, A, lb, ub, lbA, ubA = (t.cpu().numpy() for t in qp_args)
+        o = orc.default_opts(polish=0)
+        pilot = min(Bl, 4 * cores)
+        t1 = time.perf_counter()
+        orc.qp_solve_batch(H[:pilot], g[:pilot], A[:pilot], lb[:pilot], ub[:pilot], lbA[:pilot], ubA[:pilot], o, want_lambda=False)
+        rate = pilot / (time.perf_counter() - t1)
+        sample = int(max(pilot, min(Bl, rate * 15.0)))        # ~15 s of CPU work, bounded by the batch
+        t1 = time.perf_counter()
+        _, _, fl_c, it_c, _, used = orc.qp_solve_batch(H[:sample], g[:sample], A[:sample], lb[:sample], ub[:sample], lbA[:sample], ubA[:sample], o,
+                                                        want_lambda=False)
+        tc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": sample / tc, "unit": "QP solves/s", "cores": int(used), "kind": "port",
+                               "sample": "first %d instances of the same batch, same (H,g,A,bounds), oracle IPM (no polish), OpenMP over instances; "
+                                         "reference-equivalent CPU path (MATLAB+qpOASES cannot run here)" % sample,
+                               "mean_ipm_iterations": float(it_c.mean()), "solved": int((fl_c == 0).sum())}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

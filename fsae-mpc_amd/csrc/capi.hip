@@ -1,0 +1,225 @@
+// capi.hip -- the C ABI of libfsaempc.so (include/fsaempc.h).  Host-side glue only: argument checks,
+// workspace carving, kernel launches.  There is no CPU compute path: without a gfx950 device every entry
+// point fails with FSAEMPC_ERR_NODEVICE / FSAEMPC_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include "fsaempc.h"
+#include "qp_solver.h"
+#include "ltv_build.h"
+
+namespace {
+thread_local char g_err[512] = "";
+double* g_dump = nullptr; int g_dump_stage = 0, g_dump_iter = 0;
+bool g_timing = false; hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+
+int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); return code; }
+int hipfail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu || e == hipErrorInsufficientDriver)
+             ? FSAEMPC_ERR_NODEVICE : FSAEMPC_ERR_HIP;
+}
+size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+}  // namespace
+
+extern "C" {
+
+const char* fsaempc_last_error(void) { return g_err; }
+
+void fsaempc_qp_default_opts(fsaempc_qp_opts* o) {
+  if (!o) return;
+  o->tol = 1e-8; o->tol_loose = 1e-6; o->tol_x = 1e-7; o->inf_bound = 1e9; o->max_iter = 100; o->reserved = 0;
+}
+
+long long fsaempc_qp_workspace_bytes(const fsaempc_qp_desc* desc) {
+  if (!desc || desc->nV <= 0 || desc->nC < 0 || desc->batch < 0) return FSAEMPC_ERR_ARG;
+  if (desc->nV > FSAEMPC_MAX_NV) return FSAEMPC_ERR_DIM;
+  QpDims d; qp_make_dims(desc->nV, desc->nC, &d);
+  return (long long)(d.ws_per_qp * sizeof(double) * (size_t)(desc->batch > 0 ? desc->batch : 1));
+}
+
+int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc, const double* H, const double* g, const double* A,
+                                  const double* lb, const double* ub, const double* lbA, const double* ubA,
+                                  const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
+                                  double* lambda, void* workspace, long long workspace_bytes, void* stream) {
+  if (!desc || !H || !g || !lb || !ub || !x || !fval || !exitflag || !iter || !workspace) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (desc->nV <= 0 || desc->nC < 0 || desc->batch < 0) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  if (desc->nC > 0 && (!A || !lbA || !ubA)) return fail(FSAEMPC_ERR_ARG, "nC > 0 needs A, lbA, ubA");
+  if (desc->nV > FSAEMPC_MAX_NV) return fail(FSAEMPC_ERR_DIM, "nV exceeds FSAEMPC_MAX_NV");
+  if (desc->batch == 0) return 0;
+  fsaempc_qp_opts o; if (opts) o = *opts; else fsaempc_qp_default_opts(&o);
+  QpParams P; memset(&P, 0, sizeof(P));
+  qp_make_dims(desc->nV, desc->nC, &P.d);
+  if ((long long)(P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
+  if (P.d.lds_solve > 160 * 1024 || P.d.lds_prep > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of this kernel generation");
+  P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
+  P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
+  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter;
+  P.shared_HA = desc->shared_HA;
+  P.dump = g_dump; P.dump_stage = g_dump_stage & 0xff; P.dump_iter = g_dump_stage >> 8;
+  hipError_t e;
+  if (g_timing) { e = hipEventRecord(g_ev[0], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
+  e = qp_launch(P, desc->batch, (hipStream_t)stream, g_timing ? g_ev[1] : nullptr);
+  if (e != hipSuccess) return hipfail(e, "qp_launch");
+  if (g_timing) { e = hipEventRecord(g_ev[2], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
+  return 0;
+}
+
+int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc, const double* H, const double* g, const double* A,
+                           const double* lb, const double* ub, const double* lbA, const double* ubA,
+                           const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter, double* lambda) {
+  if (!desc || !H || !g || !lb || !ub || !x) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (desc->nV <= 0 || desc->nC < 0 || desc->batch < 0) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  if (desc->nC > 0 && (!A || !lbA || !ubA)) return fail(FSAEMPC_ERR_ARG, "nC > 0 needs A, lbA, ubA");
+  if (desc->nV > FSAEMPC_MAX_NV) return fail(FSAEMPC_ERR_DIM, "nV exceeds FSAEMPC_MAX_NV");
+  const size_t n = desc->nV, m = desc->nC, B = desc->batch, BH = desc->shared_HA ? 1 : B;
+  if (B == 0) return 0;
+  // the original gateway rejects NaN anywhere and Inf in H,g,A ("Argument %d contains 'NaN' !")
+  for (size_t i = 0; i < BH * n * n; ++i) if (!isfinite(H[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Argument 1 contains 'NaN' or 'Inf' !");
+  for (size_t i = 0; i < B * n; ++i) if (!isfinite(g[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Argument 2 contains 'NaN' or 'Inf' !");
+  for (size_t i = 0; i < BH * m * n; ++i) if (!isfinite(A[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Argument 3 contains 'NaN' or 'Inf' !");
+  for (size_t i = 0; i < B * n; ++i) if (isnan(lb[i]) || isnan(ub[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): bounds contain 'NaN' !");
+  for (size_t i = 0; i < B * m; ++i) if (isnan(lbA[i]) || isnan(ubA[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): constraint bounds contain 'NaN' !");
+  long long wsb = fsaempc_qp_workspace_bytes(desc);
+  if (wsb < 0) return fail((int)wsb, "workspace size");
+  const size_t szH = BH * n * n, szg = B * n, szA = BH * m * n, szm = B * m, szl = B * (n + m);
+  const size_t nd = szH + szg + szA + 2 * szg + 2 * szm + szg /*x*/ + B /*fval*/ + szl /*lambda*/;
+  char* dev = nullptr;
+  hipError_t e = hipMalloc((void**)&dev, nd * sizeof(double) + 2 * B * sizeof(int) + (size_t)wsb + 4096);
+  if (e != hipSuccess) return hipfail(e, "hipMalloc");
+  double* p = (double*)dev;
+  double* dH = p; p += szH; double* dg = p; p += szg; double* dA = p; p += szA;
+  double* dlb = p; p += szg; double* dub = p; p += szg; double* dlbA = p; p += szm; double* dubA = p; p += szm;
+  double* dx = p; p += szg; double* dfv = p; p += B; double* dlam = p; p += szl;
+  int* dfl = (int*)p; int* dit = dfl + B;
+  void* dws = (void*)(((uintptr_t)(dit + B) + 255) & ~(uintptr_t)255);
+  int rc = 0;
+#define CP(dst, src, cnt) do { if (rc == 0 && (cnt) > 0) { e = hipMemcpy(dst, src, (cnt) * sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) rc = hipfail(e, "hipMemcpy H2D"); } } while (0)
+  CP(dH, H, szH); CP(dg, g, szg); CP(dA, A, szA); CP(dlb, lb, szg); CP(dub, ub, szg); CP(dlbA, lbA, szm); CP(dubA, ubA, szm);
+#undef CP
+  if (rc == 0) rc = fsaempc_qp_solve_batch_device(desc, dH, dg, m ? dA : nullptr, dlb, dub, m ? dlbA : nullptr, m ? dubA : nullptr, opts,
+                                                  dx, dfv, dfl, dit, dlam, dws, wsb, nullptr);
+  if (rc == 0) { e = hipDeviceSynchronize(); if (e != hipSuccess) rc = hipfail(e, "solve"); }
+  if (rc == 0) {
+    (void)hipMemcpy(x, dx, szg * sizeof(double), hipMemcpyDeviceToHost);
+    if (fval) (void)hipMemcpy(fval, dfv, B * sizeof(double), hipMemcpyDeviceToHost);
+    if (exitflag) (void)hipMemcpy(exitflag, dfl, B * sizeof(int), hipMemcpyDeviceToHost);
+    if (iter) (void)hipMemcpy(iter, dit, B * sizeof(int), hipMemcpyDeviceToHost);
+    if (lambda) (void)hipMemcpy(lambda, dlam, szl * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  return rc;
+}
+
+int fsaempc_ltv_nx(int model) { return model == FSAEMPC_MODEL_KINEMATIC ? 5 : 7; }
+static int ltv_ns(int model) { return model == FSAEMPC_MODEL_KINEMATIC ? 1 : 4; }
+int fsaempc_ltv_nV(int model, int N) { return 2 * N + ltv_ns(model); }
+int fsaempc_ltv_nC(int model, int N) { return (model == FSAEMPC_MODEL_KINEMATIC ? 6 : 20) * N; }
+
+static int ltv_check(const fsaempc_ltv_desc* d, const fsaempc_spline* sp) {
+  if (!d || !sp || !sp->xP || !sp->yP) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (d->model != FSAEMPC_MODEL_KINEMATIC && d->model != FSAEMPC_MODEL_DYNAMIC) return fail(FSAEMPC_ERR_ARG, "unknown model");
+  if (d->N <= 0 || d->batch < 0 || !(d->dt > 0) || sp->M <= 0 || !(sp->dl > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  if (ltv_build_lds_bytes(fsaempc_ltv_nx(d->model), d->N, 256) > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "horizon too long for the LDS staging");
+  return 0;
+}
+
+int fsaempc_ltv_build_qp_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_spline* sp,
+                                      const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                                      double* H, double* g, double* A, double* lb, double* ub, double* lbA, double* ubA,
+                                      double* pred, double* Bt, double* qconst, void* stream) {
+  int rc = ltv_check(desc, sp); if (rc) return rc;
+  if (!x0 || !x_ref || !x_lin || !u_lin || !H || !g || !A || !lb || !ub || !lbA || !ubA || !Bt) return fail(FSAEMPC_ERR_ARG, "null argument (Bt is required as scratch)");
+  if (desc->batch == 0) return 0;
+  LtvParams P; memset(&P, 0, sizeof(P));
+  P.nx = fsaempc_ltv_nx(desc->model); P.N = desc->N; P.dt = desc->dt;
+  P.spM = sp->M; P.spdl = sp->dl; P.xP = sp->xP; P.yP = sp->yP;
+  P.x0 = x0; P.x_ref = x_ref; P.x_lin = x_lin; P.u_lin = u_lin;
+  P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA; P.pred = pred; P.Bt = Bt; P.qconst = qconst;
+  hipError_t e = ltv_build_launch(P, desc->batch, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "ltv_build_launch");
+  return 0;
+}
+
+struct LtvCarve { size_t H, g, A, lb, ub, lbA, ubA, pred, Bt, qc, z, qpws, total; };
+static void ltv_carve(const fsaempc_ltv_desc* d, LtvCarve* c) {
+  const size_t B = d->batch > 0 ? d->batch : 1, nx = fsaempc_ltv_nx(d->model), N = d->N;
+  const size_t nV = fsaempc_ltv_nV(d->model, d->N), nC = fsaempc_ltv_nC(d->model, d->N), R = nx * N;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { size_t o = off; off = align64(off + cnt * sizeof(double)); return o; };
+  c->H = take(B * nV * nV); c->g = take(B * nV); c->A = take(B * nC * nV); c->lb = take(B * nV); c->ub = take(B * nV);
+  c->lbA = take(B * nC); c->ubA = take(B * nC); c->pred = take(B * R); c->Bt = take(B * R * nV); c->qc = take(B); c->z = take(B * nV);
+  off = (off + 255) & ~(size_t)255;
+  c->qpws = off;
+  fsaempc_qp_desc q{(int)nV, (int)nC, (int)B, 0};
+  long long w = fsaempc_qp_workspace_bytes(&q);
+  c->total = off + (w > 0 ? (size_t)w : 0);
+}
+
+long long fsaempc_ltv_workspace_bytes(const fsaempc_ltv_desc* desc) {
+  if (!desc || desc->N <= 0 || desc->batch < 0) return FSAEMPC_ERR_ARG;
+  if (fsaempc_ltv_nV(desc->model, desc->N) > FSAEMPC_MAX_NV) return FSAEMPC_ERR_DIM;
+  LtvCarve c; ltv_carve(desc, &c);
+  return (long long)c.total;
+}
+
+int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_spline* sp,
+                                  const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                                  const fsaempc_qp_opts* opts, double* u_opt, double* x_opt, double* slack, double* fval,
+                                  int* exitflag, int* iter, void* workspace, long long workspace_bytes, void* stream) {
+  int rc = ltv_check(desc, sp); if (rc) return rc;
+  if (!x0 || !x_ref || !x_lin || !u_lin || !u_opt || !x_opt || !slack || !fval || !exitflag || !iter || !workspace) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (fsaempc_ltv_nV(desc->model, desc->N) > FSAEMPC_MAX_NV) return fail(FSAEMPC_ERR_DIM, "nV exceeds FSAEMPC_MAX_NV");
+  if (desc->batch == 0) return 0;
+  LtvCarve c; ltv_carve(desc, &c);
+  if ((long long)c.total > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
+  char* w = (char*)workspace;
+  auto D = [&](size_t off) { return (double*)(w + off); };
+  rc = fsaempc_ltv_build_qp_batch_device(desc, sp, x0, x_ref, x_lin, u_lin, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA),
+                                         D(c.pred), D(c.Bt), D(c.qc), stream);
+  if (rc) return rc;
+  fsaempc_qp_desc q{fsaempc_ltv_nV(desc->model, desc->N), fsaempc_ltv_nC(desc->model, desc->N), desc->batch, 0};
+  rc = fsaempc_qp_solve_batch_device(&q, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA), opts, D(c.z), fval, exitflag, iter,
+                                     nullptr, w + c.qpws, (long long)(c.total - c.qpws), stream);
+  if (rc) return rc;
+  hipError_t e = ltv_post_launch(fsaempc_ltv_nx(desc->model), desc->N, ltv_ns(desc->model), desc->batch, D(c.z), D(c.pred), D(c.Bt), D(c.qc),
+                                 u_opt, x_opt, slack, fval, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "ltv_post_launch");
+  return 0;
+}
+
+int fsaempc_selftest_mfma(void) {
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt == 0) return fail(FSAEMPC_ERR_NODEVICE, "no HIP device");
+  char msg[256] = "";
+  int bad = qp_selftest_mfma(msg, sizeof(msg));
+  if (bad != 0) snprintf(g_err, sizeof(g_err), "%s", msg);
+  return bad;
+}
+
+int fsaempc_debug_set_dump(double* out, int stage) { g_dump = out; g_dump_stage = stage; return 0; }
+
+int fsaempc_qp_set_timing(int enable) {
+  if (enable && !g_ev[0]) {
+    for (int i = 0; i < 3; ++i) { hipError_t e = hipEventCreate(&g_ev[i]); if (e != hipSuccess) return hipfail(e, "hipEventCreate"); }
+  }
+  g_timing = enable != 0;
+  return 0;
+}
+
+int fsaempc_qp_get_timing(double* prep_ms, double* solve_ms) {
+  if (!g_ev[0]) return fail(FSAEMPC_ERR_ARG, "timing was never enabled");
+  hipError_t e = hipEventSynchronize(g_ev[2]);
+  if (e != hipSuccess) return hipfail(e, "hipEventSynchronize");
+  float a = 0, b = 0;
+  e = hipEventElapsedTime(&a, g_ev[0], g_ev[1]); if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+  e = hipEventElapsedTime(&b, g_ev[1], g_ev[2]); if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+  if (prep_ms) *prep_ms = a;
+  if (solve_ms) *solve_ms = b;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// qp_solver.h -- internal interface between the C ABI (capi.hip) and the QP kernels (qp_solver.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct QpDims {
+  int n, m;        // variables, general rows
+  int T, np;       // 16-wide column tiles, padded n
+  int Kq;          // MFMA k-steps = rows per lane group = ceil(m/4)
+  int J, JB;       // owner-layout slots for rows / for variable bounds
+  int ld;          // leading dimension of the LDS normal matrix
+  int rowlen;      // (J+JB)*64
+  size_t off_Aw, off_Hw, off_gw, off_E, off_F, off_rows, off_save, ws_per_qp;  // in doubles
+  size_t lds_solve, lds_prep;                                                  // in bytes
+};
+
+struct QpParams {
+  QpDims d;
+  const double *H, *g, *A, *lb, *ub, *lbA, *ubA;
+  double* ws;
+  double *x, *fval, *lambda;
+  int *exitflag, *iter;
+  double tol, tol_loose, tol_x, inf_bound;
+  int max_iter, shared_HA;
+  double* dump; int dump_stage, dump_iter;
+};
+
+void qp_make_dims(int n, int m, QpDims* d);
+hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid = nullptr);
+int qp_selftest_mfma(char* msg, int msglen);

@@ -1,0 +1,110 @@
+"""Host-side mirror of the reference's solver interface
+    [x,fval,exitflag,iter,lambda,auxOutput] = qpOASES(H,g,A,lb,ub,lbA,ubA{,options})
+(optimizers/matlab/qpOASES/qpOASES.m:22-23, bounds-only form :34-35, multi-column form :65-67),
+running on the MI355X through libfsaempc.so.  Same argument meaning, same exit flags; the build's
+additive extension is a leading batch dimension (3-D H / A)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import QpDesc, check, default_opts, lib
+
+
+def _col(a, n, name):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a[:, None]
+    if a.shape[0] != n:
+        raise ValueError("ERROR (qpOASES): Input dimension mismatch for argument %s" % name)
+    return a
+
+
+def qpOASES(H, g, *args, options=None):
+    """qpOASES(H,g,A,lb,ub,lbA,ubA) or qpOASES(H,g,lb,ub).  g/lb/ub/lbA/ubA may have k columns => k QPs
+    sharing H and A (qpOASES.m:65-67).  H (nV,nV[,B]) / A (nC,nV[,B]) with a trailing batch axis => B
+    independent QPs.  Returns x, fval, exitflag, iter, lambda, auxOutput (arrays gain a trailing batch axis
+    when more than one QP is solved)."""
+    if len(args) == 5:
+        A, lb, ub, lbA, ubA = args
+    elif len(args) == 2:
+        lb, ub = args
+        A, lbA, ubA = None, None, None
+    else:
+        raise TypeError("qpOASES(H,g,A,lb,ub,lbA,ubA) or qpOASES(H,g,lb,ub)")
+    H = np.asarray(H, dtype=np.float64)
+    nV = H.shape[0]
+    if H.shape[1] != nV:
+        raise ValueError("ERROR (qpOASES): Input dimension mismatch for argument 1")
+    batched_HA = H.ndim == 3
+    g = _col(g, nV, "2")
+    B = H.shape[2] if batched_HA else g.shape[1]
+    lb, ub = _col(lb, nV, "lb"), _col(ub, nV, "ub")
+    if A is None or np.size(A) == 0:
+        nC = 0
+        A3 = np.zeros((0, nV, 1))
+        lbA = ubA = np.zeros((0, B))
+    else:
+        A = np.asarray(A, dtype=np.float64)
+        nC = A.shape[0]
+        if A.shape[1] != nV:
+            raise ValueError("ERROR (qpOASES): Input dimension mismatch for argument 3")
+        A3 = A if A.ndim == 3 else A[:, :, None]
+        lbA, ubA = _col(lbA, nC, "lbA"), _col(ubA, nC, "ubA")
+
+    def bcast(a):
+        return np.broadcast_to(a, (a.shape[0], B)) if a.shape[1] != B else a
+
+    g, lb, ub, lbA, ubA = (bcast(a) for a in (g, lb, ub, lbA, ubA))
+    # instance-major stacking, each instance column-major
+    Hs = np.ascontiguousarray(np.transpose(H if batched_HA else H[:, :, None], (2, 1, 0)))
+    As = np.ascontiguousarray(np.transpose(A3, (2, 1, 0)))
+    vec = lambda a: np.ascontiguousarray(a.T)
+    gs, lbs, ubs, lbAs, ubAs = vec(g), vec(lb), vec(ub), vec(lbA), vec(ubA)
+    x = np.zeros((B, nV)); fval = np.zeros(B); flag = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    lam = np.zeros((B, nV + nC))
+    desc = QpDesc(nV, nC, B, 0 if batched_HA else 1)
+    opts = options if options is not None else default_opts()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().fsaempc_qp_solve_batch(C.byref(desc), p(Hs), p(gs), p(As), p(lbs), p(ubs), p(lbAs), p(ubAs), C.byref(opts),
+                                      p(x), p(fval), p(flag), p(it), p(lam))
+    check(rc, "qpOASES")
+    # working sets in the reference's encoding (qpOASES.m:58-61), derived from the multipliers
+    ws = np.sign(lam) * -1.0
+    ws[np.abs(lam) <= 1e-9 * np.maximum(1.0, np.abs(lam).max(axis=1, keepdims=True))] = 0.0
+    aux = {"workingSetB": ws[:, :nV].T.squeeze(), "workingSetC": ws[:, nV:].T.squeeze(), "cpuTime": None}
+    if B == 1:
+        return x[0], float(fval[0]), int(flag[0]), int(it[0]), lam[0], aux
+    return x.T, fval, flag, it, lam.T, aux
+
+
+def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=False, workspace=None, stream=None,
+                          shared_HA=False):
+    """Device-resident batched solve on torch CUDA(HIP) tensors (instance-major, each instance column-major):
+    H (B,nV,nV), g (B,nV), A (B,nV,nC) [memory of a column-major nC x nV matrix], lb/ub (B,nV), lbA/ubA (B,nC).
+    Asynchronous on `stream` (default: torch's current stream).  Returns dict of device tensors."""
+    import torch
+    B, nV = g.shape
+    nC = lbA.shape[1] if lbA is not None else 0
+    dev = g.device
+    for t in (H, g, A, lb, ub, lbA, ubA):
+        if t is not None and (t.dtype != torch.float64 or not t.is_contiguous() or not t.is_cuda):
+            raise ValueError("device tensors must be contiguous float64 on the GPU")
+    desc = QpDesc(nV, nC, B, 1 if shared_HA else 0)
+    need = lib().fsaempc_qp_workspace_bytes(C.byref(desc))
+    if need < 0:
+        check(int(need), "fsaempc_qp_workspace_bytes")
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 7) // 8, dtype=torch.float64, device=dev)
+    x = torch.empty((B, nV), dtype=torch.float64, device=dev)
+    fval = torch.empty(B, dtype=torch.float64, device=dev)
+    flag = torch.empty(B, dtype=torch.int32, device=dev)
+    it = torch.empty(B, dtype=torch.int32, device=dev)
+    lam = torch.empty((B, nV + nC), dtype=torch.float64, device=dev) if want_lambda else None
+    opts = options if options is not None else default_opts()
+    st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    rc = lib().fsaempc_qp_solve_batch_device(C.byref(desc), P(H), P(g), P(A), P(lb), P(ub), P(lbA), P(ubA), C.byref(opts),
+                                             P(x), P(fval), P(flag), P(it), P(lam), P(workspace),
+                                             C.c_longlong(workspace.numel() * 8), C.c_void_p(st))
+    check(rc, "fsaempc_qp_solve_batch_device")
+    return dict(x=x, fval=fval, exitflag=flag, iter=it, lam=lam, workspace=workspace)

@@ -1,0 +1,153 @@
+/*
+ * fsaempc.h -- C ABI of libfsaempc.so: the MI355X (gfx950) batched LTV-MPC QP path.
+ *
+ * This library is the drop-in for the ONE hot path of kerry-he/fsae-mpc:
+ *   linearise -> condense -> build QP -> solve -> post-solve, for many independent instances.
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * reference repo).  Plain C types only; device entry points take raw device pointers and a
+ * hipStream_t passed as void*.  All matrices are column-major (MATLAB layout); a batch is
+ * stacked instance-major (instance b starts at b * <elements per instance>).
+ *
+ * Return value of every function: 0 on success, <0 = FSAEMPC_ERR_* (argument / runtime
+ * errors -- the analogue of the MEX gateway's mexErrMsgTxt, never a solver outcome).
+ * Solver outcomes are per-instance exit flags with qpOASES semantics
+ * (optimizers/matlab/qpOASES/qpOASES.m:43-47): 0 solved, 1 iteration limit,
+ * -1 internal error, -2 infeasible, -3 unbounded.
+ */
+#ifndef FSAEMPC_H
+#define FSAEMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSAEMPC_ERR_ARG      (-1)  /* bad argument (null pointer, negative size, NaN in data ...) */
+#define FSAEMPC_ERR_DIM      (-2)  /* unsupported dimension (nV > FSAEMPC_MAX_NV) */
+#define FSAEMPC_ERR_HIP      (-3)  /* HIP runtime error (see fsaempc_last_error) */
+#define FSAEMPC_ERR_NODEVICE (-4)  /* no gfx950 device / code object not loadable: there is NO CPU fallback */
+#define FSAEMPC_ERR_WORKSPACE (-5) /* workspace too small */
+
+#define FSAEMPC_MAX_NV 128
+
+#define FSAEMPC_MODEL_KINEMATIC 0  /* mpc/ltv/kinematic/ltvmpc_kinetmatic_curvilinear.m */
+#define FSAEMPC_MODEL_DYNAMIC   1  /* mpc/ltv/dynamic/ltvmpc_dynamic_curvilinear.m */
+
+/* Solver options; the reference passes none (=> qpOASES defaults, qpOASES_options.m:180-213).
+ * fsaempc_qp_default_opts fills the defaults of this build. */
+typedef struct {
+  double tol;        /* strict relative KKT tolerance (default 1e-8) */
+  double tol_loose;  /* fall-back KKT tolerance = the specified 1e-6 */
+  double tol_x;      /* Newton-decrement test on the affine direction (default 1e-7) */
+  double inf_bound;  /* |bound| >= inf_bound is treated as infinite (default 1e9; covers the
+                        reference's +-1e10 fillers, kinematic_state_constraints.m:38-39) */
+  int    max_iter;   /* interior-point iteration limit (default 100) */
+  int    reserved;
+} fsaempc_qp_opts;
+
+void fsaempc_qp_default_opts(fsaempc_qp_opts* o);
+
+/* Problem descriptor of one batched solve.
+ * shared_HA != 0: H and A are given once and shared by all `batch` instances (the reference
+ * API's own multi-column form, qpOASES.m:65-67); otherwise H and A are stacked per instance. */
+typedef struct {
+  int nV;        /* number of variables */
+  int nC;        /* number of general constraint rows (0 => bounds-only form, qpOASES.m:34-35) */
+  int batch;     /* number of independent QPs */
+  int shared_HA;
+} fsaempc_qp_desc;
+
+/* Bytes of device workspace fsaempc_qp_solve_batch_device needs for `desc`. */
+long long fsaempc_qp_workspace_bytes(const fsaempc_qp_desc* desc);
+
+/*
+ * Replaces: [x,fval,exitflag,iter,lambda] = qpOASES(H,g,A,lb,ub,lbA,ubA)
+ *           optimizers/matlab/qpOASES/qpOASES.m:22-23 (call sites
+ *           mpc/ltv/kinematic/ltvmpc_kinetmatic_curvilinear.m:52,
+ *           mpc/ltv/dynamic/ltvmpc_dynamic_curvilinear.m:52), batched.
+ * Device pointers, asynchronous on `stream`.  H: nV*nV, g: nV, A: nC*nV (column-major),
+ * lb/ub: nV, lbA/ubA: nC per instance; +-inf allowed in bounds.
+ * Outputs: x nV, fval 1, exitflag 1 (int), iter 1 (int) per instance; lambda (nV+nC per
+ * instance, bounds first, >=0 lower side / <=0 upper side) may be NULL.
+ * `workspace` must hold fsaempc_qp_workspace_bytes(desc) bytes.
+ */
+int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc,
+                                  const double* H, const double* g, const double* A,
+                                  const double* lb, const double* ub, const double* lbA, const double* ubA,
+                                  const fsaempc_qp_opts* opts,
+                                  double* x, double* fval, int* exitflag, int* iter, double* lambda,
+                                  void* workspace, long long workspace_bytes, void* stream);
+
+/* Same call on host pointers: copies to the device, solves, copies back, synchronises.
+ * This is what a MEX gateway calls (mex/qpOASES.cpp); validates like the original gateway
+ * (NaN anywhere / Inf in H,g,A => FSAEMPC_ERR_ARG). */
+int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc,
+                           const double* H, const double* g, const double* A,
+                           const double* lb, const double* ub, const double* lbA, const double* ubA,
+                           const fsaempc_qp_opts* opts,
+                           double* x, double* fval, int* exitflag, int* iter, double* lambda);
+
+/* ---- LTV-MPC step (QP construction + solve + post-solve) ---------------------------------- */
+
+/* Track spline table: the `kappa` closure of main.m:18 as data.  xP,yP: M x 4 column-major. */
+typedef struct {
+  int M;
+  double dl;
+  const double* xP;   /* device pointers for *_device entry points, host pointers otherwise */
+  const double* yP;
+} fsaempc_spline;
+
+typedef struct {
+  int model;     /* FSAEMPC_MODEL_* */
+  int N;         /* horizon steps (main.m:36) */
+  int batch;
+  double dt;     /* main.m:37 */
+} fsaempc_ltv_desc;
+
+int fsaempc_ltv_nx(int model);            /* 5 / 7 */
+int fsaempc_ltv_nV(int model, int N);     /* 2N + slack count */
+int fsaempc_ltv_nC(int model, int N);     /* 6N / 20N */
+
+/*
+ * Replaces the QP construction of ltvmpc_*_curvilinear.m:38-41 (rk2/rk4 lineariser,
+ * sequential_integration.m, *_state_constraints.m, generate_qp.m), batched, on device.
+ * Inputs per instance: x0 nx, x_ref nx*N, x_lin nx*N, u_lin 2*N.
+ * Outputs per instance: H,g,A,lb,ub,lbA,ubA as for the solver; pred = [A_bar*x0 + d_bar] (nx*N),
+ * Bt (nx*N x nV, B_bar with slack columns), qconst 1.  Bt/pred/qconst may be NULL.
+ */
+int fsaempc_ltv_build_qp_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_spline* sp,
+                                      const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                                      double* H, double* g, double* A, double* lb, double* ub, double* lbA, double* ubA,
+                                      double* pred, double* Bt, double* qconst, void* stream);
+
+/* Bytes of device workspace for fsaempc_ltv_step_batch_device (QP tensors + solver workspace). */
+long long fsaempc_ltv_workspace_bytes(const fsaempc_ltv_desc* desc);
+
+/*
+ * Replaces [u_opt,x_opt,QP,exitflag,fval,slack_opt] = ltvmpc_*_curvilinear(x0,x_ref,kappa,dt,x_lin,u_lin,QP)
+ * (ltvmpc_kinetmatic_curvilinear.m:1, ltvmpc_dynamic_curvilinear.m:1), batched, on device.
+ * Outputs per instance: u_opt 2N, x_opt nx*N, slack ns, fval 1 (incl. the constant, :60), exitflag, iter.
+ */
+int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_spline* sp,
+                                  const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                                  const fsaempc_qp_opts* opts,
+                                  double* u_opt, double* x_opt, double* slack, double* fval, int* exitflag, int* iter,
+                                  void* workspace, long long workspace_bytes, void* stream);
+
+/* ---- diagnostics ---------------------------------------------------------------------------- */
+const char* fsaempc_last_error(void);
+/* Runs the on-device fp64 MFMA layout self-test (v_mfma_f64_16x16x4_f64 operand / accumulator
+ * lane maps the kernels rely on).  Returns 0 if the hardware matches, >0 number of mismatches. */
+int fsaempc_selftest_mfma(void);
+/* Debug hook used by the parity tests: dumps solver internals of instance 0 after `stage`
+ * (see qp_solver.hip) into `out` (device pointer, >= 4*nV*nV+8*(nV+nC) doubles). */
+int fsaempc_debug_set_dump(double* out, int stage);
+
+/* Kernel timing with HIP events recorded on the launch stream of the last fsaempc_qp_solve_batch_device
+ * call (prep = scaling/repack kernel, solve = interior-point kernel).  get_timing synchronises on the events. */
+int fsaempc_qp_set_timing(int enable);
+int fsaempc_qp_get_timing(double* prep_ms, double* solve_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

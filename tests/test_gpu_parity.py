@@ -1,0 +1,242 @@
+"""GPU parity tests (run on a real MI355X with -m gpu).  Everything calls through the C ABI of libfsaempc.so;
+the oracle (oracle/) is only the checker.  Tolerances (floating point, stated per SURVEY 8c / north_star):
+  * QP construction (H,g,A,bounds): relative 1e-9 of the tensor's max magnitude (same arithmetic, different
+    summation order than the reference's dense D matrix / BLAS products).
+  * QP solve: KKT certificate <= 1e-6 (the specified tolerance), fval within 1e-7 relative of the oracle's
+    certified optimum, x within X_TOL relative (interior-point iterate vs vertex-exact polish; the 1e8 slack
+    cost leaves flat directions)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from conftest import golden_files, relerr
+
+pytestmark = pytest.mark.gpu
+
+KKT_TOL = 1e-6
+FVAL_TOL = 1e-7
+X_TOL = 2e-3      # worst case over a batch
+X_TOL_P90 = 1e-5  # 90th percentile over a batch
+
+
+@pytest.fixture(scope="module")
+def fm():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import fsae_mpc_amd
+    return fsae_mpc_amd
+
+
+@pytest.fixture(scope="module")
+def torch_():
+    import torch
+    return torch
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _solve_dev(fm, torch, q, **kw):
+    out = fm.qp_solve_batch_device(_dev(torch, q["H"]), _dev(torch, q["g"]), _dev(torch, q["A"]), _dev(torch, q["lb"]), _dev(torch, q["ub"]),
+                                   _dev(torch, q["lbA"]), _dev(torch, q["ubA"]), want_lambda=True, **kw)
+    torch.cuda.synchronize()
+    return {k: (v.cpu().numpy() if v is not None and k != "workspace" else v) for k, v in out.items()}
+
+
+def test_00_mfma_layout_selftest(fm):
+    assert fm.lib().fsaempc_selftest_mfma() == 0, fm.lib().fsaempc_last_error()
+
+
+def test_01_normal_matrix_dump_matches_numpy(fm, torch_, orc, otrack):
+    """First iteration internals of instance 0: M = H~ + diag + A~'DA~ (MFMA path), p1..p3, Hx against numpy."""
+    torch = torch_
+    N = 12
+    x0, xl, ul, xr = orc.synth_instances(0, N, 0.05, otrack.L, 20190, [1, 2])
+    q = orc.build_qp_batch(0, otrack, N, 0.05, x0, xr, xl, ul)
+    n, m = q["g"].shape[1], q["lbA"].shape[1]
+    dump = torch.zeros(4 * n * n + 8 * (n + m), dtype=torch.float64, device="cuda")
+    fm.lib().fsaempc_debug_set_dump(C.c_void_p(dump.data_ptr()), 1)
+    try:
+        _solve_dev(fm, torch, q)
+    finally:
+        fm.lib().fsaempc_debug_set_dump(None, 0)
+    d = dump.cpu().numpy()
+    M = d[: n * n].reshape(n, n)
+    H, g, A = q["H"][0].T, q["g"][0], q["A"][0].T
+    hd = np.diag(H)
+    E = np.where(hd > 1e-12, 1 / np.sqrt(np.maximum(hd, 1e-300)), 1 / np.abs(A).max(axis=0))
+    F = 1 / np.abs(A * E).max(axis=1)
+    Hs, gs, As = H * E[:, None] * E[None, :], g * E, A * F[:, None] * E[None, :]
+    l = np.concatenate([q["lb"][0] / E, q["lbA"][0] * F]); u = np.concatenate([q["ub"][0] / E, q["ubA"][0] * F])
+    hl = np.concatenate([q["lb"][0], q["lbA"][0]]) > -1e9; hu = np.concatenate([q["ub"][0], q["ubA"][0]]) < 1e9
+    x = np.clip(np.zeros(n), np.where(hl[:n], l[:n], -np.inf), np.where(hu[:n], u[:n], np.inf))
+    G = np.vstack([np.eye(n), As]); v = G @ x
+    tl = np.where(hl, np.maximum(v - np.where(hl, l, 0), 1), 1); tu = np.where(hu, np.maximum(np.where(hu, u, 0) - v, 1), 1)
+    zl = hl * 1.0; zu = hu * 1.0
+    r = Hs @ x + gs - As.T @ (zl[n:] - zu[n:])
+    zl[:n] = np.where(hl[:n], np.maximum(r, 0) + 1, 0); zu[:n] = np.where(hu[:n], np.maximum(-r, 0) + 1, 0)
+    D = np.where(hl, zl / tl, 0) + np.where(hu, zu / tu, 0)
+    Mref = Hs + G.T @ (D[:, None] * G)
+    assert np.max(np.abs(M - Mref)) <= 1e-11 * np.abs(Mref).max()
+    rpl = np.where(hl, v - np.where(hl, l, 0) - tl, 0); rpu = np.where(hu, np.where(hu, u, 0) - v - tu, 0)
+    w1 = np.where(hl, -(zl / tl) * rpl, 0) + np.where(hu, (zu / tu) * rpu, 0)
+    w2 = np.where(hl, 1 / tl, 0) - np.where(hu, 1 / tu, 0)
+    for k, w in enumerate((w1, w2, zl - zu)):
+        got = d[n * n + k * n: n * n + (k + 1) * n]
+        ref = As.T @ w[n:]
+        assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.abs(ref).max()), k
+    assert np.max(np.abs(d[n * n + 3 * n: n * n + 4 * n] - Hs @ x)) <= 1e-11 * max(1.0, np.abs(Hs @ x).max())
+
+
+def test_known_answer_qps_through_the_mirror(fm):
+    H = 2 * np.eye(2); g = np.array([-2., -4.])
+    x, f, fl, it, lam, aux = fm.qpOASES(H, g, [0, 0], [1.5, 1.5])          # bounds-only form (qpOASES.m:34-35)
+    assert fl == 0 and np.allclose(x, [1, 1.5], atol=1e-7) and np.isclose(f, -4.75) and lam[1] < 0
+    assert aux["workingSetB"][1] == 1 and aux["workingSetB"][0] == 0
+    x, f, fl, it, lam, aux = fm.qpOASES(H, g, np.array([[1., 1.]]), [0, 0], [1.5, 1.5], [-np.inf], [2.0])
+    assert fl == 0 and np.allclose(x, [0.5, 1.5], atol=1e-6) and np.isclose(f, -4.5, atol=1e-6)
+    # infeasible -> -2 ; x is NaN like a failed MEX call leaves it undefined
+    x, f, fl, it, lam, aux = fm.qpOASES(np.eye(1), [0.], np.array([[1.]]), [1.], [np.inf], [-np.inf], [-1.])
+    assert fl == -2
+    assert fm.qpOASES(np.eye(1), [0.], [1.], [0.])[2] == -2
+    # multi-column form: k QPs sharing H and A (qpOASES.m:65-67)
+    G = np.array([[-2., 0.], [-4., -4.]])
+    x, f, fl, it, lam, aux = fm.qpOASES(H, G, np.array([[1., 1.]]), np.zeros((2, 1)), np.full((2, 1), 1.5), [-np.inf], [2.0])
+    assert (fl == 0).all() and np.allclose(x[:, 0], [0.5, 1.5], atol=1e-6) and np.allclose(x[:, 1], [0, 1.5], atol=1e-6)
+    # slack-pattern QP (linear penalty on a zero-curvature variable)
+    x, f, fl, it, lam, aux = fm.qpOASES(np.diag([2., 0.]), [0., 100.], np.array([[1., 1.]]), [-10, 0], [10, np.inf], [3.], [np.inf])
+    assert fl == 0 and np.allclose(x, [3, 0], atol=1e-6)
+
+
+@pytest.mark.parametrize("path", golden_files())
+def test_golden_fixtures(fm, torch_, orc, path):
+    """Committed fixtures: construction and solution of the HIP path against the recorded oracle outputs."""
+    torch = torch_
+    z = np.load(path)
+    tr = fm.Track.load(path.split("/")[-1].split("_")[0])
+    model, N = int(z["model"]), int(z["N"])
+    B = len(z["ids"])
+    stepper = fm.LtvBatch(model, N, 0.05, tr, B)
+    q = stepper.build_qp(_dev(torch, z["x0"]), _dev(torch, z["x_ref"]), _dev(torch, z["x_lin"]), _dev(torch, z["u_lin"]))
+    torch.cuda.synchronize()
+    for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA", "const"):
+        assert relerr(q[k].cpu().numpy(), z[k]) <= 1e-9, k
+    out = stepper.step(_dev(torch, z["x0"]), _dev(torch, z["x_ref"]), _dev(torch, z["x_lin"]), _dev(torch, z["u_lin"]))
+    torch.cuda.synchronize()
+    assert (out["exitflag"].cpu().numpy() == 0).all()
+    fv = out["fval"].cpu().numpy()
+    assert np.max(np.abs(fv - z["fval_step"]) / np.maximum(1, np.abs(z["fval_step"]))) <= FVAL_TOL
+    for k in ("u_opt", "x_opt", "slack"):
+        a, b = out[k].cpu().numpy(), z[k]
+        assert np.max(np.abs(a - b)) <= X_TOL * max(1.0, np.abs(b).max()), k
+
+
+@pytest.mark.parametrize("model,N,B", [(0, 40, 256), (0, 20, 64), (1, 40, 48), (1, 60, 12)])
+def test_construction_parity(fm, torch_, orc, model, N, B):
+    torch = torch_
+    tr = fm.Track.load("fsg2019"); otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 20190, range(B))
+    stepper = fm.LtvBatch(model, N, 0.05, tr, B)
+    q = stepper.build_qp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul))
+    torch.cuda.synchronize()
+    ref = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul, keep_prediction=True)
+    for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA", "const", "Bt"):
+        assert relerr(q[k].cpu().numpy(), ref[k]) <= 1e-9, k
+    pred = np.einsum("bcr,bc->br", ref["A_bar"], x0) + ref["d_bar"]
+    assert relerr(q["pred"].cpu().numpy(), pred) <= 1e-9
+
+
+@pytest.mark.parametrize("model,N,B", [(0, 40, 512), (0, 20, 128), (1, 40, 96), (1, 60, 24)])
+def test_solve_parity_generic_mode(fm, torch_, orc, model, N, B):
+    """Identical (H,g,A,bounds) to the oracle and to the HIP solver (generic mode of SURVEY 8d)."""
+    torch = torch_
+    otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, otr.L, 20190, range(B))
+    q = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul)
+    out = _solve_dev(fm, torch, q)
+    xo, fo, flo, ito, lamo, _ = orc.qp_solve_batch(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"])
+    assert (flo == 0).all()
+    assert (out["exitflag"] == 0).all(), np.unique(out["exitflag"], return_counts=True)
+    kkt = np.array([orc.qp_kkt(q["H"][b].T, q["g"][b], q["A"][b].T, q["lb"][b], q["ub"][b], q["lbA"][b], q["ubA"][b], out["x"][b], out["lam"][b])[0]
+                    for b in range(B)])
+    assert kkt.max() <= KKT_TOL, kkt.max()
+    assert np.max(np.abs(out["fval"] - fo) / np.maximum(1, np.abs(fo))) <= FVAL_TOL
+    ex = np.abs(out["x"] - xo).max(axis=1) / np.maximum(1, np.abs(xo).max(axis=1))
+    assert ex.max() <= X_TOL and np.percentile(ex, 90) <= X_TOL_P90, (ex.max(), np.percentile(ex, 90))
+    assert abs(out["iter"].mean() - ito.mean()) < 3.0   # same algorithm, same iteration profile
+
+
+def test_fused_step_parity(fm, torch_, orc):
+    torch = torch_
+    otr = orc.Track.load(fm.tracks._HERE + "/tracks/fss2019.json")
+    tr = fm.Track.load("fss2019")
+    for model, N, B in ((0, 40, 32), (1, 40, 16)):
+        x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 7, range(B))
+        out = fm.LtvBatch(model, N, 0.05, tr, B).step(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul))
+        torch.cuda.synchronize()
+        assert (out["exitflag"].cpu().numpy() == 0).all()
+        for b in range(0, B, 5):
+            u, xo, s, f, fl, it = orc.ltv_step(model, otr, N, 0.05, x0[b], xr[b].T, xl[b].T, ul[b].T)
+            assert fl == 0
+            assert abs(out["fval"][b].item() - f) <= FVAL_TOL * max(1, abs(f))
+            assert np.max(np.abs(out["u_opt"][b].cpu().numpy() - u)) <= X_TOL * max(1, np.abs(u).max())
+            assert np.max(np.abs(out["x_opt"][b].cpu().numpy() - xo)) <= X_TOL * max(1, np.abs(xo).max())
+    # the single-instance mirror of the reference driver signature
+    x0, xl, ul, xr = fm.instances(0, 20, 0.05, tr.L, 3, [0])
+    u_opt, x_opt, QP, flag, fval, slack = fm.ltvmpc_kinetmatic_curvilinear(x0[0], xr[0].T, tr, 0.05, xl[0].T, ul[0].T, 0)
+    u, xo, s, f, fl, it = orc.ltv_step(0, otr, 20, 0.05, x0[0], xr[0].T, xl[0].T, ul[0].T)
+    assert flag == 0 and QP == 0 and abs(fval - f) <= FVAL_TOL * max(1, abs(f)) and np.allclose(u_opt, u, atol=X_TOL * 10)
+
+
+def test_full_size_config2_properties(fm, torch_, orc):
+    """BASELINE config 2 (B=4096, kinematic N=40): size-independent properties -- every instance solved, the
+    KKT certificate on a sample, bitwise run-to-run determinism, and invariance to batch position (index-pure)."""
+    torch = torch_
+    tr = fm.Track.load("fsg2019")
+    B, N = 4096, 40
+    x0, xl, ul, xr = fm.instances(0, N, 0.05, tr.L, 20190, range(B))
+    stepper = fm.LtvBatch(0, N, 0.05, tr, B)
+    q = stepper.build_qp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul))
+    a = fm.qp_solve_batch_device(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"], want_lambda=True)
+    b = fm.qp_solve_batch_device(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"], want_lambda=True)
+    torch.cuda.synchronize()
+    assert (a["exitflag"] == 0).all().item()
+    assert torch.equal(a["x"], b["x"]) and torch.equal(a["fval"], b["fval"]) and torch.equal(a["iter"], b["iter"])
+    H, g, A = q["H"].cpu().numpy(), q["g"].cpu().numpy(), q["A"].cpu().numpy()
+    lb, ub, lbA, ubA = (q[k].cpu().numpy() for k in ("lb", "ub", "lbA", "ubA"))
+    x, lam = a["x"].cpu().numpy(), a["lam"].cpu().numpy()
+    for i in range(0, B, 97):
+        assert orc.qp_kkt(H[i].T, g[i], A[i].T, lb[i], ub[i], lbA[i], ubA[i], x[i], lam[i])[0] <= KKT_TOL
+    # a shard of the batch gives bit-identical per-instance results (what the multi-GPU split relies on)
+    sl = slice(1000, 1512)
+    c = fm.qp_solve_batch_device(*(q[k][sl].contiguous() for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")))
+    torch.cuda.synchronize()
+    assert torch.equal(c["x"], a["x"][sl])
+
+
+def test_edge_cases(fm, torch_):
+    torch = torch_
+    # nV = 1, nC = 0 ; empty batch ; nV = 128 (FSAEMPC_MAX_NV) with random SPD data ; ragged tile sizes
+    x, f, fl, it, lam, aux = fm.qpOASES(np.array([[2.0]]), [-2.0], [-5.0], [5.0])
+    assert fl == 0 and np.allclose(x, [1.0], atol=1e-8)
+    d = fm._lib.QpDesc(3, 0, 0, 0)
+    one = torch.zeros(16, dtype=torch.float64, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert fm.lib().fsaempc_qp_solve_batch_device(C.byref(d), P(one), P(one), None, P(one), P(one), None, None, None, P(one), P(one), P(one), P(one),
+                                                  None, P(one), C.c_longlong(128), None) == 0
+    rng = np.random.default_rng(5)
+    for n, m in ((128, 40), (17, 33), (33, 5), (64, 64)):
+        Q = rng.normal(size=(n, n)); H = Q @ Q.T + n * np.eye(n); g = rng.normal(size=n) * 10
+        A = rng.normal(size=(m, n)); xs = rng.normal(size=n)
+        lbA = A @ xs - rng.uniform(0.1, 1, m); ubA = A @ xs + rng.uniform(0.1, 1, m)
+        lbA[::3] = -np.inf; ubA[1::3] = np.inf
+        lb = xs - 1; ub = xs + 1; ub[::2] = np.inf
+        x, f, fl, it, lam, aux = fm.qpOASES(H, g, A, lb, ub, lbA, ubA)
+        assert fl == 0
+        import oracle as orc
+        assert orc.qp_kkt(H, g, A, lb, ub, lbA, ubA, x, lam)[0] <= KKT_TOL
+        xo, fo, flo, _, _ = orc.qp_solve(H, g, A, lb, ub, lbA, ubA)
+        assert abs(f - fo) <= FVAL_TOL * max(1, abs(fo)) and np.max(np.abs(x - xo)) <= 1e-5 * max(1, np.abs(xo).max())
+    with pytest.raises(fm.FsaempcError):
+        fm.qpOASES(np.eye(130), np.zeros(130), np.zeros(130), np.ones(130))   # > FSAEMPC_MAX_NV fails loudly
