@@ -14,10 +14,16 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h include/fsa
 $(LIBDIR)/libfsaempc.so: $(LIBDIR)/qp_solver.o $(LIBDIR)/ltv_build.o $(LIBDIR)/capi.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
+# diagnostic build with in-kernel phase stamps (never benchmarked; see tools/phase_profile.py)
+stamps: $(LIBDIR)/libfsaempc_stamps.so
+$(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/capi.hip
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
 	rm -rf $(LIBDIR)/*.o $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean stamps

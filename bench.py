@@ -124,17 +124,18 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         import oracle as orc
         otr = orc.Track.load(os.path.join(ROOT, "fsae-mpc_amd", "tracks", "fsg2019.json"))
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        cores = min(cores, 16)   # the GPU box's CPU share for one GPU
         H, g, A, lb, ub, lbA, ubA = (t.cpu().numpy() for t in qp_args)
         o = orc.default_opts(polish=0)
         pilot = min(Bl, 4 * cores)
         t1 = time.perf_counter()
-        orc.qp_solve_batch(H[:pilot], g[:pilot], A[:pilot], lb[:pilot], ub[:pilot], lbA[:pilot], ubA[:pilot], o, want_lambda=False)
+        orc.qp_solve_batch(H[:pilot], g[:pilot], A[:pilot], lb[:pilot], ub[:pilot], lbA[:pilot], ubA[:pilot], o, threads=cores, want_lambda=False)
         rate = pilot / (time.perf_counter() - t1)
         sample = int(max(pilot, min(Bl, rate * 15.0)))        # ~15 s of CPU work, bounded by the batch
         t1 = time.perf_counter()
         _, _, fl_c, it_c, _, used = orc.qp_solve_batch(H[:sample], g[:sample], A[:sample], lb[:sample], ub[:sample], lbA[:sample], ubA[:sample], o,
-                                                        want_lambda=False)
+                                                        threads=cores, want_lambda=False)
         tc = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": sample / tc, "unit": "QP solves/s", "cores": int(used), "kind": "port",
                                "sample": "first %d instances of the same batch, same (H,g,A,bounds), oracle IPM (no polish), OpenMP over instances; "

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfsaempc.so")
+LIB_PATH = os.environ.get("FSAEMPC_LIB") or os.path.join(_HERE, "lib", "libfsaempc.so")
 
 EXPORTS = [
     "fsaempc_qp_default_opts", "fsaempc_qp_workspace_bytes", "fsaempc_qp_solve_batch_device", "fsaempc_qp_solve_batch",

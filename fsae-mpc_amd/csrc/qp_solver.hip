@@ -183,7 +183,7 @@ struct Ctx {
   double* Ms;    // LDS n x ld
   double* vec;   // LDS n-vectors, np each
 };
-enum RowArr { R_L = 0, R_U, R_TL, R_TU, R_ZL, R_ZU, R_V, R_D, R_W1, R_W2, R_W3, R_VA, R_VC, R_RPL, R_RPU, R_NARR };
+enum RowArr { R_L = 0, R_U, R_TL, R_TU, R_ZL, R_ZU, R_V, R_D, R_W1, R_W2, R_W3, R_VA, R_VC, R_RPL, R_RPU, R_CB1, R_CC1, R_CB2, R_CC2, R_NARR };
 enum VecArr { V_X = 0, V_G, V_HX, V_R1, V_R2, V_P1, V_P2, V_P3, V_DX, V_E, V_NARR };
 
 DEVINL double* rowp(const Ctx& k, int arr) { return k.rows + (size_t)arr * k.rowlen; }
@@ -194,22 +194,34 @@ DEVINL bool row_valid(const Ctx& k, int js) {
   return (js - k.J) * 64 + k.lane < k.n;
 }
 
-// Hx through the full symmetric tile grid (runtime loop over tile rows keeps the register footprint small)
+// Hx through the full symmetric tile grid; the loads of tile row I+1 are in flight while row I is consumed
 template <int T> DEVINL void hx_tiles(const Ctx& k, const double* X, double* HX) {
-  double hx[T];
+  double hx[T], hn[T][4], hc[T][4];
 #pragma unroll
   for (int t = 0; t < T; ++t) hx[t] = 0.0;
+#pragma unroll
+  for (int Jt = 0; Jt < T; ++Jt)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) hn[Jt][p] = k.Hw[((size_t)Jt * 4 + p) * 64 + k.lane];
 #pragma unroll 1
   for (int I = 0; I < T; ++I) {
+#pragma unroll
+    for (int Jt = 0; Jt < T; ++Jt)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) hc[Jt][p] = hn[Jt][p];
+    if (I + 1 < T) {
+#pragma unroll
+      for (int Jt = 0; Jt < T; ++Jt)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) hn[Jt][p] = k.Hw[((size_t)((I + 1) * T + Jt) * 4 + p) * 64 + k.lane];
+    }
     double xk[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) xk[p] = X[16 * I + k.q + 4 * p];
 #pragma unroll
-    for (int Jt = 0; Jt < T; ++Jt) {
-      const double* hp = k.Hw + ((size_t)(I * T + Jt) * 4) * 64 + k.lane;
+    for (int Jt = 0; Jt < T; ++Jt)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) hx[Jt] = fma(hp[p * 64], xk[p], hx[Jt]);
-    }
+      for (int p = 0; p < 4; ++p) hx[Jt] = fma(hc[Jt][p], xk[p], hx[Jt]);
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -276,38 +288,73 @@ template <int T> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, doubl
   }
 }
 
-// y = A~ v for NV vectors (LDS n-vectors) -> owner-layout row arrays
-template <int T, int NVEC> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout) {
-  double v[NVEC][T];
+// y = A~ v for NVEC vectors (LDS n-vectors) -> owner-layout row arrays.  FUSE: the first vector is the affine
+// direction; as soon as a row's va = a_r' dxa is reduced, the second-order weight
+//   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
+// is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
+template <int T, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor) {
+  double v[NVEC][T], pc[T], bn[T], bc[T];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e)
 #pragma unroll
     for (int t = 0; t < T; ++t) v[e][t] = vin[e][16 * t + k.c];
-  for (int js = 0; js < k.J; ++js) {
-    double keep[NVEC];
 #pragma unroll
-    for (int e = 0; e < NVEC; ++e) keep[e] = 0.0;
-    const int smax = min(16, k.Kq - 16 * js);
-    for (int cc = 0; cc < smax; ++cc) {
-      const int s = 16 * js + cc;
-      double bc[T];
+  for (int t = 0; t < T; ++t) { pc[t] = 0.0; bn[t] = 0.0; }
+  const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
+  const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
+  double a1n = 0, b1n = 0, c1n = 0, a2n = 0, b2n = 0, c2n = 0;
+  if (k.Kq > 0) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) bc[t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
+    for (int t = 0; t < T; ++t) bn[t] = k.Aw[(size_t)t * 64 + k.lane];
+    if (FUSE) { const int ri = k.q * 16; a1n = CA1[ri]; b1n = CB1[ri]; c1n = CC1[ri]; a2n = CA2[ri]; b2n = CB2[ri]; c2n = CC2[ri]; }
+  }
+  double keep[NVEC];
 #pragma unroll
-      for (int e = 0; e < NVEC; ++e) {
-        double dsum = 0.0;
+  for (int e = 0; e < NVEC; ++e) keep[e] = 0.0;
+  for (int s = 0; s < k.Kq; ++s) {
+    const double a1 = a1n, b1 = b1n, c1 = c1n, a2 = a2n, b2 = b2n, c2 = c2n;
 #pragma unroll
-        for (int t = 0; t < T; ++t) dsum = fma(bc[t], v[e][t], dsum);
-        dsum = grp16_sum(dsum);
-        if (k.c == cc) keep[e] = dsum;
+    for (int t = 0; t < T; ++t) bc[t] = bn[t];
+    if (s + 1 < k.Kq) {
+      const int s1 = s + 1;
+#pragma unroll
+      for (int t = 0; t < T; ++t) bn[t] = k.Aw[((size_t)s1 * T + t) * 64 + k.lane];
+      if (FUSE) {
+        const int ri = (s1 >> 4) * 64 + k.q * 16 + (s1 & 15);
+        a1n = CA1[ri]; b1n = CB1[ri]; c1n = CC1[ri]; a2n = CA2[ri]; b2n = CB2[ri]; c2n = CC2[ri];
       }
     }
+    const int cc = s & 15;
 #pragma unroll
-    for (int e = 0; e < NVEC; ++e) rout[e][js * 64 + k.lane] = keep[e];
+    for (int e = 0; e < NVEC; ++e) {
+      double dsum = 0.0;
+#pragma unroll
+      for (int t = 0; t < T; ++t) dsum = fma(bc[t], v[e][t], dsum);
+      dsum = grp16_sum(dsum);
+      if (k.c == cc) keep[e] = dsum;
+      if (FUSE && e == 0) {
+        const double dl_ = dsum + a1, du_ = a2 - dsum;
+        const double w = dl_ * fma(c1, dl_, b1) - du_ * fma(c2, du_, b2);
+#pragma unroll
+        for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[t], pc[t]);
+      }
+    }
+    if (cc == 15 || s + 1 == k.Kq) {
+      const int js = s >> 4;
+#pragma unroll
+      for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
+    }
+  }
+  if (FUSE) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double pv = q_sum(pc[t]);
+      if (k.q == 0) Pcor[16 * t + k.c] = pv;
+    }
   }
 }
 
-// p = A~' w (w: owner-layout row array) -> LDS n-vector
+// p = A~' w (w: owner-layout row array) -> LDS n-vector (only used by the initial point)
 template <int T> DEVINL void pass_Atw(const Ctx& k, const double* W, double* Pout) {
   double p[T];
 #pragma unroll
@@ -324,109 +371,162 @@ template <int T> DEVINL void pass_Atw(const Ctx& k, const double* W, double* Pou
   }
 }
 
-// accumulators (upper tiles, C/D layout) -> LDS lower triangle, row-major: Ms[i*ld + j], i >= j
-template <int T> DEVINL void acc_to_lds(const Ctx& k, const v4d* acc) {
+// ---------------------------------------------------------------------------------------------
+// Register-resident blocked Cholesky M = U'U and triangular solves on the matrix cores.
+//
+// A 16x16 tile X held in accumulator (C/D) layout -- lane (c,q), reg p <-> X[q+4p][c] -- can be fed straight
+// back as an MFMA operand: as the A operand it acts as X' (A[i][k] = X[k][i]), as the B operand as X.  Four
+// MFMAs (p = 0..3) therefore compute X'Y for any two resident tiles with no data movement, which is all an
+// upper-form blocked Cholesky needs:  U_KJ = U_KK^-T M_KJ (done as row operations on the whole block row),
+// M_IJ -= U_KI' U_KJ.  Right-hand sides ride along as one more tile column (16 slots), so the forward solve
+// U'y = b is a by-product of the factorisation.  The backward solve U x = y needs U_KJ' tiles; those are
+// transposed one at a time through a 2 KiB LDS scratch.
+// ---------------------------------------------------------------------------------------------
+template <int T> DEVINL void mfma4_sub(const v4d& X, const v4d& Y, v4d& Dst) {  // Dst -= X' Y
 #pragma unroll
-  for (int I = 0; I < T; ++I)
+  for (int p = 0; p < 4; ++p) Dst = __builtin_amdgcn_mfma_f64_16x16x4f64(-X[p], Y[p], Dst, 0, 0, 0);
+}
+DEVINL v4d mfma4_new(const v4d& X, const v4d& Y) {  // X' Y
+  v4d Z = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int Jt = I; Jt < T; ++Jt)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int a = 16 * I + k.q + 4 * p;  // row of the upper tile element
-        const int bcol = 16 * Jt + k.c;      // its column;  M[a][bcol] == M[bcol][a], stored at row bcol
-        if (bcol < k.n && a <= bcol) k.Ms[bcol * k.ld + a] = acc[Tri<T>::idx(I, Jt)][p];
-      }
+  for (int p = 0; p < 4; ++p) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(X[p], Y[p], Z, 0, 0, 0);
+  return Z;
 }
 
-// in-LDS Cholesky of the n x n lower triangle, one wave.  Returns 0 ok / 1 non-finite pivot.
-DEVINL int chol_lds(const Ctx& k, double floor_abs) {
+// tile transpose through the LDS scratch: returns Z with Z[row][col] = X[col][row] (C/D layout both sides)
+DEVINL v4d tile_transpose(const Ctx& k, double* scratch, const v4d& Xt) {
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) scratch[(k.q + 4 * p) * 17 + k.c] = Xt[p];
+  __syncthreads();
+  v4d Z;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) Z[p] = scratch[k.c * 17 + k.q + 4 * p];
+  return Z;
+}
+
+// Factorise one 16x16 diagonal tile D = U'U in place by 16 row steps (4 panels x 4 rows; the rows of later panels
+// are updated by one K=4 MFMA per panel) and apply the same row operations to two companion tiles: Yk (enters as
+// the identity, leaves as U^-T) and the right-hand-side tile rk (leaves as U^-T rk).  Only these three tiles see
+// VALU work; every other tile of the factorisation is touched by the matrix cores alone.
+DEVINL int diag_factor(const Ctx& k, v4d& Ud, v4d& Yk, v4d& rk, double floor_abs) {
   int bad = 0;
-  for (int j = 0; j < k.n; ++j) {
-    const double* rowj = k.Ms + j * k.ld;
-    double s[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = k.lane + 64 * h;
-      double acc = 0.0;
-      if (i >= j && i < k.n) {
-        const double* rowi = k.Ms + i * k.ld;
-        acc = rowi[j];
-        int kk = 0;
-        for (; kk + 1 < j; kk += 2) { acc = fma(-rowi[kk], rowj[kk], acc); acc = fma(-rowi[kk + 1], rowj[kk + 1], acc); }
-        if (kk < j) acc = fma(-rowi[kk], rowj[kk], acc);
-      }
-      s[h] = acc;
+  for (int p = 0; p < 4; ++p) {
+#pragma unroll 1
+    for (int qq = 0; qq < 4; ++qq) {
+      const int kk = 4 * p + qq;
+      double d = rl(Ud[p], 16 * qq + kk);
+      if (!(d > floor_abs)) { if (!(fabs(d) < INFINITY)) bad = 1; d = floor_abs; }
+      const double rinv = 1.0 / sqrt(d);
+      const double f = (k.q == qq) ? rinv : 1.0;
+      Ud[p] *= f; Yk[p] *= f; rk[p] *= f;
+      double coef = 0.0;
+      for (int q2 = qq + 1; q2 < 4; ++q2) { const double sc = rl(Ud[p], 16 * qq + 4 * p + q2); coef = (k.q == q2) ? sc : coef; }
+      const int src = k.c + 16 * qq;
+      const double u = __shfl(Ud[p], src), y = __shfl(Yk[p], src), r = __shfl(rk[p], src);
+      Ud[p] = fma(-coef, u, Ud[p]); Yk[p] = fma(-coef, y, Yk[p]); rk[p] = fma(-coef, r, rk[p]);
     }
-    double piv = rl(j < 64 ? s[0] : s[1], j & 63);
-    if (!(piv > floor_abs)) { if (!(fabs(piv) < INFINITY)) bad = 1; piv = floor_abs; }
-    const double inv = 1.0 / sqrt(piv);
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = k.lane + 64 * h;
-      if (i == j) k.Ms[i * k.ld + j] = piv * inv;  // sqrt(piv)
-      else if (i > j && i < k.n) k.Ms[i * k.ld + j] = s[h] * inv;
+    if (p < 3) {
+      const double a = (k.c > 4 * p + 3) ? -Ud[p] : 0.0;
+      Yk = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yk[p], Yk, 0, 0, 0);
+      rk = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rk[p], rk, 0, 0, 0);
+      Ud = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Ud[p], Ud, 0, 0, 0);
     }
-    __syncthreads();
   }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) if (k.c < k.q + 4 * p) Ud[p] = 0.0;   // strictly lower part only ever held the symmetric copy
   return bad;
 }
 
-// solve L L' x = r for NR right-hand sides held in LDS n-vectors (in place); x kept in registers during sweeps
-template <int NR> DEVINL void chol_solve_lds(const Ctx& k, double* const* R) {
-  double r[NR][2];
+// Blocked Cholesky of acc (upper tiles) in place.  Yt[K] = U_KK^-T and Wt[K] = U_KK^-1 are kept for the solves;
+// rh rides along and leaves as y = U^-T b.
+template <int T, int K> struct FactorStep {
+  static DEVINL int run(const Ctx& k, v4d* acc, v4d* Yt, v4d* Wt, v4d* rh, double* scratch, double floor_abs) {
+    v4d Yk;
 #pragma unroll
-  for (int e = 0; e < NR; ++e)
+    for (int p = 0; p < 4; ++p) Yk[p] = (k.q + 4 * p == k.c) ? 1.0 : 0.0;
+    int bad = diag_factor(k, acc[Tri<T>::idx(K, K)], Yk, rh[K], floor_abs);
+    const v4d Wk = tile_transpose(k, scratch, Yk);
+    Yt[K] = Yk; Wt[K] = Wk;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { const int i = k.lane + 64 * h; r[e][h] = i < k.n ? R[e][i] : 0.0; }
-  double dg[2];
+    for (int Jt = K + 1; Jt < T; ++Jt) acc[Tri<T>::idx(K, Jt)] = mfma4_new(Wk, acc[Tri<T>::idx(K, Jt)]);   // U_KJ = U_KK^-T M_KJ
 #pragma unroll
-  for (int h = 0; h < 2; ++h) { const int i = k.lane + 64 * h; dg[h] = i < k.n ? 1.0 / k.Ms[i * k.ld + i] : 0.0; }
-  // forward: L y = r  (column oriented; column kk of L is read with stride ld)
-  for (int kk = 0; kk < k.n; ++kk) {
-    const double dk = rl(kk < 64 ? dg[0] : dg[1], kk & 63);
-    double y[NR];
+    for (int I = K + 1; I < T; ++I) {
+      const v4d& UKI = acc[Tri<T>::idx(K, I)];
 #pragma unroll
-    for (int e = 0; e < NR; ++e) y[e] = rl(kk < 64 ? r[e][0] : r[e][1], kk & 63) * dk;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = k.lane + 64 * h;
-      if (i > kk && i < k.n) {
-        const double lik = k.Ms[i * k.ld + kk];
-#pragma unroll
-        for (int e = 0; e < NR; ++e) r[e][h] = fma(-lik, y[e], r[e][h]);
-      } else if (i == kk) {
-#pragma unroll
-        for (int e = 0; e < NR; ++e) r[e][h] = y[e];
-      }
+      for (int Jt = I; Jt < T; ++Jt) mfma4_sub<T>(UKI, acc[Tri<T>::idx(K, Jt)], acc[Tri<T>::idx(I, Jt)]);
+      mfma4_sub<T>(UKI, rh[K], rh[I]);
     }
+    return bad | FactorStep<T, K + 1>::run(k, acc, Yt, Wt, rh, scratch, floor_abs);
   }
-  // backward: L' x = y  (row kk of L is contiguous)
-  for (int kk = k.n - 1; kk >= 0; --kk) {
-    const double dk = rl(kk < 64 ? dg[0] : dg[1], kk & 63);
-    double x[NR];
-#pragma unroll
-    for (int e = 0; e < NR; ++e) x[e] = rl(kk < 64 ? r[e][0] : r[e][1], kk & 63) * dk;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = k.lane + 64 * h;
-      if (i < kk) {
-        const double lki = k.Ms[kk * k.ld + i];
-#pragma unroll
-        for (int e = 0; e < NR; ++e) r[e][h] = fma(-lki, x[e], r[e][h]);
-      } else if (i == kk) {
-#pragma unroll
-        for (int e = 0; e < NR; ++e) r[e][h] = x[e];
-      }
-    }
-  }
-#pragma unroll
-  for (int e = 0; e < NR; ++e)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { const int i = k.lane + 64 * h; if (i < k.n) R[e][i] = r[e][h]; }
+};
+template <int T> struct FactorStep<T, T> {
+  static DEVINL int run(const Ctx&, v4d*, v4d*, v4d*, v4d*, double*, double) { return 0; }
+};
+template <int T> DEVINL int reg_factor(const Ctx& k, v4d* acc, v4d* Yt, v4d* Wt, v4d* rh, double* scratch, double floor_abs) {
+  return FactorStep<T, 0>::run(k, acc, Yt, Wt, rh, scratch, floor_abs);
 }
 
-struct RowSide { double t, z, dt, dz; };
+// forward solve U'y = b on a fresh right-hand-side tile column: y_K = U_KK^-T (b_K - sum_{I<K} U_IK' y_I)
+template <int T> DEVINL void reg_forward(const Ctx& k, const v4d* acc, const v4d* Wt, v4d* rh) {
+#pragma unroll
+  for (int K = 0; K < T; ++K) {
+    rh[K] = mfma4_new(Wt[K], rh[K]);
+#pragma unroll
+    for (int I = K + 1; I < T; ++I) mfma4_sub<T>(acc[Tri<T>::idx(K, I)], rh[K], rh[I]);
+  }
+}
+
+// backward solve U x = y in place: x_K = U_KK^-1 (y_K - sum_{J>K} U_KJ x_J); U_KJ' comes through the LDS scratch
+template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const v4d* Yt, v4d* rh, double* scratch) {
+#pragma unroll
+  for (int K = T - 1; K >= 0; --K) {
+#pragma unroll
+    for (int Jt = K + 1; Jt < T; ++Jt) {
+      const v4d Lt = tile_transpose(k, scratch, acc[Tri<T>::idx(K, Jt)]);   // Lt[kappa][i] = U_KJ[i][kappa]
+      mfma4_sub<T>(Lt, rh[Jt], rh[K]);
+    }
+    rh[K] = mfma4_new(Yt[K], rh[K]);                                         // (U_KK^-T)' = U_KK^-1
+  }
+}
+
+// right-hand sides: LDS n-vectors -> slot `slot` of the rhs tile column, and back
+template <int T> DEVINL void rhs_load(const Ctx& k, v4d* rh, const double* v0, const double* v1) {
+#pragma unroll
+  for (int K = 0; K < T; ++K)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int i = 16 * K + k.q + 4 * p;
+      double v = 0.0;
+      if (k.c == 0) v = v0[i];
+      if (v1 && k.c == 1) v = v1[i];
+      rh[K][p] = v;
+    }
+}
+template <int T> DEVINL void rhs_store(const Ctx& k, const v4d* rh, double* v0, double* v1) {
+#pragma unroll
+  for (int K = 0; K < T; ++K)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int i = 16 * K + k.q + 4 * p;
+      if (k.c == 0) v0[i] = rh[K][p];
+      if (v1 && k.c == 1) v1[i] = rh[K][p];
+    }
+}
+
+#ifndef QP_STAMPS
+#define QP_STAMPS 0
+#endif
+#if QP_STAMPS
+#define STAMP_DECL unsigned long long st_acc[16]; for (int i_ = 0; i_ < 16; ++i_) st_acc[i_] = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define STAMP(id) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[id] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_OUT do { if (P.dump && P.dump_stage == 9 && lane == 0) for (int i_ = 0; i_ < 16; ++i_) P.dump[(size_t)b * 16 + i_] = (double)st_acc[i_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(id) do { } while (0)
+#define STAMP_OUT do { } while (0)
+#endif
 
 template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams P) {
   const int b = blockIdx.x;
@@ -438,7 +538,8 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw;
   k.rows = ws + d.off_rows; k.rowlen = d.rowlen;
   extern __shared__ double lds[];
-  k.Ms = lds; k.vec = lds + (size_t)d.n * d.ld;
+  k.Ms = nullptr; k.vec = lds;
+  double* SCR = lds + (size_t)V_NARR * d.np;   // 16 x 17 tile-transpose scratch
   const double* gw = ws + d.off_gw;
   const double* Es = ws + d.off_E;
   const double* Fs = ws + d.off_F;
@@ -501,6 +602,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   infeas = wave_max((double)infeas) > 0;
   __syncthreads();
 
+  STAMP_DECL
   int flag = 1, it = 0;
   double fval_s = 0.0;
   if (infeas) { flag = -2; }
@@ -508,7 +610,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   // ---- v = G x ----
   {
     const double* vin[1] = {X}; double* rout[1] = {aV};
-    pass_Av<T, 1>(k, vin, rout);
+    pass_Av<T, 1, false>(k, vin, rout, nullptr);
     for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aV[(J + jb) * 64 + lane] = i < n ? X[i] : 0.0; }
   }
   // ---- initial slacks / multipliers: t = max(resid,1), z = 1 on general rows ----
@@ -546,6 +648,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   double* XS = ws + d.off_save;            // np
   double* LAMS = ws + d.off_save + k.np;   // rowlen
 
+  STAMP(0);
   for (it = 0; flag == 1; ++it) {
     // ================= row phase 1: residuals, weights =================
     double s_gap = 0, m_rp = 0;
@@ -558,6 +661,8 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       const double rpl = hl ? v - l - tl : 0.0, rpu = hu ? u - v - tu : 0.0;
       const double dl_ = hl ? zl / tl : 0.0, du_ = hu ? zu / tu : 0.0;
       aRPL[ix] = rpl; aRPU[ix] = rpu;
+      rowp(k, R_CB1)[ix] = dl_; rowp(k, R_CC1)[ix] = hl ? dl_ / tl : 0.0;
+      rowp(k, R_CB2)[ix] = du_; rowp(k, R_CC2)[ix] = hu ? du_ / tu : 0.0;
       aD[ix] = dl_ + du_;
       aW1[ix] = -dl_ * rpl + du_ * rpu;                              // affine rhs weight
       aW2[ix] = (hl ? 1.0 / tl : 0.0) - (hu ? 1.0 / tu : 0.0);      // centering weight (times sigma*mu)
@@ -572,12 +677,15 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     const double rp_rel = wave_max(m_rp);
     __syncthreads();
 
+    STAMP(1);
     // ================= pass 1: M = H + A'DA (MFMA), p1, p2, p3; Hx =================
     hx_tiles<T>(k, X, HX);
+    STAMP(2);
     v4d acc[NT];
     acc_init<T>(k, acc);
     pass_syrk<T>(k, acc, P1, P2, P3);
     __syncthreads();
+    STAMP(3);
     // objective, dual residual
     double fl = 0, m_rd = 0;
     for (int h = 0; h < 2; ++h) {
@@ -604,39 +712,49 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     } else if (have_saved && merit > P.tol_loose) { flag = 2; break; }
     if (merit < 0.9 * best_res) { best_res = merit; stall = 0; } else ++stall;
 
-    // ================= factorise =================
-    acc_to_lds<T>(k, acc);
-    __syncthreads();
+    // ================= factorise (registers, MFMA) with the affine / centering right-hand sides riding along =================
     double dmax_l = 0;
-    for (int h = 0; h < 2; ++h) {
-      const int i = lane + 64 * h;
-      if (i < n) {
-        const int ix = (J + (i >> 6)) * 64 + (i & 63);
-        const double mii = k.Ms[i * k.ld + i] + aD[ix];
-        k.Ms[i * k.ld + i] = mii;
-        dmax_l = fmax(dmax_l, mii);
-      }
+#pragma unroll
+    for (int K = 0; K < T; ++K) {
+      const int i = 16 * K + k.c;                       // diagonal element of tile (K,K) lives on lane c with q = c&3, reg c>>2
+      const int ix = (J + (i >> 6)) * 64 + (i & 63);
+      const double dadd = i < n ? aD[ix] : 1.0;         // padded indices get a unit diagonal
+      const bool mine = (k.q == (k.c & 3));
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (mine && p == (k.c >> 2)) { acc[Tri<T>::idx(K, K)][p] += dadd; dmax_l = fmax(dmax_l, acc[Tri<T>::idx(K, K)][p]); }
     }
     const double dmax = wave_max(dmax_l);
-    __syncthreads();
-    if (P.dump && b == 0 && P.dump_stage == 1 && it == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
-      for (int i = lane; i < n * n; i += 64) { const int r = i / n, cc = i % n; P.dump[i] = r >= cc ? k.Ms[r * k.ld + cc] : k.Ms[cc * k.ld + r]; }
-      for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
-    }
-    if (chol_lds(k, 1e-30 * dmax)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
-
-    // ================= affine + centering directions =================
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
-      if (i < n) {
+      if (i < k.np) {
         const int ix = (J + (i >> 6)) * 64 + (i & 63);
-        R1[i] = -(HX[i] + G[i]) + P1[i] + aW1[ix];
-        R2[i] = P2[i] + aW2[ix];
+        R1[i] = i < n ? -(HX[i] + G[i]) + P1[i] + aW1[ix] : 0.0;
+        R2[i] = i < n ? P2[i] + aW2[ix] : 0.0;
       }
     }
     __syncthreads();
-    { double* R[2] = {R1, R2}; chol_solve_lds<2>(k, R); }
+    if (P.dump && b == 0 && P.dump_stage == 1 && it == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int Jt = I; Jt < T; ++Jt)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int r = 16 * I + k.q + 4 * p, cc = 16 * Jt + k.c;
+            if (r < n && cc < n) { P.dump[r * n + cc] = acc[Tri<T>::idx(I, Jt)][p]; if (I != Jt || cc >= r) P.dump[cc * n + r] = acc[Tri<T>::idx(I, Jt)][p]; }
+          }
+      for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
+    }
+    STAMP(4);
+    v4d rh[T], Yt[T], Wt[T];
+    rhs_load<T>(k, rh, R1, R2);
+    if (reg_factor<T>(k, acc, Yt, Wt, rh, SCR, 1e-30 * dmax)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
+    STAMP(5);
+    reg_backward<T>(k, acc, Yt, rh, SCR);
+    rhs_store<T>(k, rh, R1, R2);
     __syncthreads();
+    STAMP(6);
     if (P.dump && b == 0 && P.dump_stage == 2 && it == P.dump_iter) {
       for (int i = lane; i < n; i += 64) { P.dump[i] = R1[i]; P.dump[n + i] = R2[i]; }
     }
@@ -654,13 +772,14 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     // ================= pass 2: va = G dxa, vc = G dxc =================
     {
       const double* vin[2] = {R1, R2}; double* rout[2] = {aVA, aVC};
-      pass_Av<T, 2>(k, vin, rout);
+      pass_Av<T, 2, true>(k, vin, rout, P1);   // fused: P1 = A~' w_cor
       for (int jb = 0; jb < k.JB; ++jb) {
         const int i = jb * 64 + lane;
         aVA[(J + jb) * 64 + lane] = i < n ? R1[i] : 0.0;
         aVC[(J + jb) * 64 + lane] = i < n ? R2[i] : 0.0;
       }
     }
+    STAMP(7);
     // ================= row phase 2: affine step length, sigma, corrector weights =================
     double a_aff = 1.0;
     for (int js = 0; js < JT; ++js) {
@@ -718,22 +837,29 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       aW1[ix] = w;
     }
     __syncthreads();
-    // ================= pass 3: p = A' w_cor ; solve for the corrector part =================
-    pass_Atw<T>(k, aW1, P1);
-    __syncthreads();
+    STAMP(8);
+    // ================= corrector: P1 = A' w_cor came out of the fused pass 2 =================
+    STAMP(9);
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
-      if (i < n) { const int ix = (J + (i >> 6)) * 64 + (i & 63); DX[i] = P1[i] + aW1[ix]; }
+      if (i < k.np) { const int ix = (J + (i >> 6)) * 64 + (i & 63); DX[i] = i < n ? P1[i] + aW1[ix] : 0.0; }
     }
     __syncthreads();
-    { double* R[1] = {DX}; chol_solve_lds<1>(k, R); }
+    {
+      rhs_load<T>(k, rh, DX, nullptr);
+      reg_forward<T>(k, acc, Wt, rh);
+      reg_backward<T>(k, acc, Yt, rh, SCR);
+      rhs_store<T>(k, rh, DX, nullptr);
+    }
     __syncthreads();
+    STAMP(10);
     // ================= pass 4: G dx_cor =================
     {
       const double* vin[1] = {DX}; double* rout[1] = {aW2};  // W2 reused for G dx_cor
-      pass_Av<T, 1>(k, vin, rout);
+      pass_Av<T, 1, false>(k, vin, rout, nullptr);
       for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aW2[(J + jb) * 64 + lane] = i < n ? DX[i] : 0.0; }
     }
+    STAMP(11);
     // full direction dx = dxa + smu*dxc + dxcor ; dv likewise
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
@@ -834,6 +960,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     }
     xn = wave_max(xn); zn = wave_max(zn);
     __syncthreads();
+    STAMP(12);
     // divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47)
     if (xn > 1e13) { flag = -3; break; }
     if (zn > 1e15 && rp_rel > 1e-6) { flag = -2; break; }
@@ -877,6 +1004,8 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < n) fl += 0.5 * X[i] * HX[i] + G[i] * X[i]; }
     fval_s = wave_sum(fl);
   }
+  STAMP(13);
+  STAMP_OUT;
   if (lane == 0) {
     P.fval[b] = have_x ? fval_s : NAN;
     P.exitflag[b] = flag;
@@ -946,7 +1075,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->off_save = off; off += d->np + d->rowlen;
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
-  d->lds_solve = ((size_t)n * d->ld + (size_t)V_NARR * d->np) * sizeof(double);
+  d->lds_solve = ((size_t)V_NARR * d->np + 16 * 17 + 16) * sizeof(double);
   d->lds_prep = ((size_t)d->np + 16 * (size_t)(4 * d->Kq + 1)) * sizeof(double);
 }
 
@@ -967,6 +1096,9 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   if (e != hipSuccess) return e;
   if (ev_mid) { e = hipEventRecord(ev_mid, st); if (e != hipSuccess) return e; }
   switch (P.d.T) {
+#ifdef QP_ONLY_T
+    case QP_ONLY_T: return launch_solve_T<QP_ONLY_T>(P, batch, st);
+#else
     case 1: return launch_solve_T<1>(P, batch, st);
     case 2: return launch_solve_T<2>(P, batch, st);
     case 3: return launch_solve_T<3>(P, batch, st);
@@ -975,6 +1107,7 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     case 6: return launch_solve_T<6>(P, batch, st);
     case 7: return launch_solve_T<7>(P, batch, st);
     case 8: return launch_solve_T<8>(P, batch, st);
+#endif
     default: return hipErrorInvalidValue;
   }
 }
