@@ -48,8 +48,16 @@ DEVINL double wave_min(double v) {
   for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
   return v;
 }
-DEVINL double grp16_sum(double v) {  // sum over the 16 lanes sharing l>>4
-  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+template <int CTRL> DEVINL double dpp_f64(double v) {  // data-parallel-primitive lane move of both halves (VALU speed, no LDS)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+DEVINL double grp16_sum(double v) {  // sum over the 16 lanes sharing l>>4 (one DPP row); every lane gets the total
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
   return v;
 }
 DEVINL double q_sum(double v) {  // sum over the 4 lane groups (same l&15)
@@ -243,42 +251,51 @@ template <int T> DEVINL void acc_init(const Ctx& k, v4d* acc) {
     }
 }
 
-// pass 1: acc += A~' D A~ on the matrix cores; p1 = A~'w1, p2 = A~'w2, p3 = A~'w3 on the VALU beside them
+// pass 1: acc += A~' D A~ on the matrix cores; p1 = A~'w1, p2 = A~'w2, p3 = A~'w3 on the VALU beside them.
+// A ring of PF k-steps of operands is kept in flight (L2 / Infinity-Cache latency under load is ~2-3k cycles,
+// one k-step of MFMA work is ~1.3k cycles).
 template <int T> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, double* P2, double* P3) {
+  constexpr int PF = 3;
   const double* D = rowp(k, R_D); const double* W1 = rowp(k, R_W1);
   const double* W2 = rowp(k, R_W2); const double* W3 = rowp(k, R_W3);
-  double p1[T], p2[T], p3[T], bn[T], bc[T];
+  double p1[T], p2[T], p3[T], bq[PF][T], cq[PF][4];
 #pragma unroll
-  for (int t = 0; t < T; ++t) { p1[t] = 0; p2[t] = 0; p3[t] = 0; bn[t] = 0; }
-  double dn = 0, w1n = 0, w2n = 0, w3n = 0;
-  if (k.Kq > 0) {
+  for (int t = 0; t < T; ++t) { p1[t] = 0; p2[t] = 0; p3[t] = 0; }
+  auto issue = [&](int u, int s) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bn[t] = k.Aw[(size_t)t * 64 + k.lane];
-    const int ri = k.q * 16;
-    dn = D[ri]; w1n = W1[ri]; w2n = W2[ri]; w3n = W3[ri];
-  }
-  for (int s = 0; s < k.Kq; ++s) {
-    const double dd = dn, w1 = w1n, w2 = w2n, w3 = w3n;
+    for (int t = 0; t < T; ++t) bq[u][t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
+    const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+    cq[u][0] = D[ri]; cq[u][1] = W1[ri]; cq[u][2] = W2[ri]; cq[u][3] = W3[ri];
+  };
 #pragma unroll
-    for (int t = 0; t < T; ++t) bc[t] = bn[t];
-    if (s + 1 < k.Kq) {  // prefetch the next k-step while the matrix cores work on this one
-      const int s1 = s + 1;
+  for (int u = 0; u < PF; ++u) {
+    if (u < k.Kq) issue(u, u);
+    else {
 #pragma unroll
-      for (int t = 0; t < T; ++t) bn[t] = k.Aw[((size_t)s1 * T + t) * 64 + k.lane];
-      const int ri = (s1 >> 4) * 64 + k.q * 16 + (s1 & 15);
-      dn = D[ri]; w1n = W1[ri]; w2n = W2[ri]; w3n = W3[ri];
+      for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
+      cq[u][0] = cq[u][1] = cq[u][2] = cq[u][3] = 0.0;
     }
-    double a[T];
+  }
+  for (int s0 = 0; s0 < k.Kq; s0 += PF) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) a[t] = dd * bc[t];
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      if (s < k.Kq) {
+        double bc[T], a[T];
+        const double dd = cq[u][0], w1 = cq[u][1], w2 = cq[u][2], w3 = cq[u][3];
 #pragma unroll
-    for (int I = 0; I < T; ++I)
+        for (int t = 0; t < T; ++t) { bc[t] = bq[u][t]; a[t] = dd * bc[t]; }
+        if (s + PF < k.Kq) issue(u, s + PF);
 #pragma unroll
-      for (int Jt = I; Jt < T; ++Jt)
-        acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], bc[Jt], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
+        for (int I = 0; I < T; ++I)
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      p1[t] = fma(w1, bc[t], p1[t]); p2[t] = fma(w2, bc[t], p2[t]); p3[t] = fma(w3, bc[t], p3[t]);
+          for (int Jt = I; Jt < T; ++Jt)
+            acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], bc[Jt], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          p1[t] = fma(w1, bc[t], p1[t]); p2[t] = fma(w2, bc[t], p2[t]); p3[t] = fma(w3, bc[t], p3[t]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -293,56 +310,66 @@ template <int T> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, doubl
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
 template <int T, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor) {
-  double v[NVEC][T], pc[T], bn[T], bc[T];
+  constexpr int PF = 4;   // k-steps of operands in flight (little compute per step => latency bound otherwise)
+  double v[NVEC][T], pc[T], bq[PF][T], cq[PF][6];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e)
 #pragma unroll
     for (int t = 0; t < T; ++t) v[e][t] = vin[e][16 * t + k.c];
 #pragma unroll
-  for (int t = 0; t < T; ++t) { pc[t] = 0.0; bn[t] = 0.0; }
+  for (int t = 0; t < T; ++t) pc[t] = 0.0;
   const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
   const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
-  double a1n = 0, b1n = 0, c1n = 0, a2n = 0, b2n = 0, c2n = 0;
-  if (k.Kq > 0) {
+  auto issue = [&](int u, int s) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bn[t] = k.Aw[(size_t)t * 64 + k.lane];
-    if (FUSE) { const int ri = k.q * 16; a1n = CA1[ri]; b1n = CB1[ri]; c1n = CC1[ri]; a2n = CA2[ri]; b2n = CB2[ri]; c2n = CC2[ri]; }
+    for (int t = 0; t < T; ++t) bq[u][t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
+    if (FUSE) {
+      const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+      cq[u][0] = CA1[ri]; cq[u][1] = CB1[ri]; cq[u][2] = CC1[ri]; cq[u][3] = CA2[ri]; cq[u][4] = CB2[ri]; cq[u][5] = CC2[ri];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) cq[u][e] = 0.0;
+    if (u < k.Kq) issue(u, u);
   }
   double keep[NVEC];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e) keep[e] = 0.0;
-  for (int s = 0; s < k.Kq; ++s) {
-    const double a1 = a1n, b1 = b1n, c1 = c1n, a2 = a2n, b2 = b2n, c2 = c2n;
+  for (int s0 = 0; s0 < k.Kq; s0 += PF) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bc[t] = bn[t];
-    if (s + 1 < k.Kq) {
-      const int s1 = s + 1;
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      if (s < k.Kq) {
+        double bc[T];
+        const double a1 = cq[u][0], b1 = cq[u][1], c1 = cq[u][2], a2 = cq[u][3], b2 = cq[u][4], c2 = cq[u][5];
 #pragma unroll
-      for (int t = 0; t < T; ++t) bn[t] = k.Aw[((size_t)s1 * T + t) * 64 + k.lane];
-      if (FUSE) {
-        const int ri = (s1 >> 4) * 64 + k.q * 16 + (s1 & 15);
-        a1n = CA1[ri]; b1n = CB1[ri]; c1n = CC1[ri]; a2n = CA2[ri]; b2n = CB2[ri]; c2n = CC2[ri];
+        for (int t = 0; t < T; ++t) bc[t] = bq[u][t];
+        if (s + PF < k.Kq) issue(u, s + PF);
+        const int cc = s & 15;
+#pragma unroll
+        for (int e = 0; e < NVEC; ++e) {
+          double dsum = 0.0;
+#pragma unroll
+          for (int t = 0; t < T; ++t) dsum = fma(bc[t], v[e][t], dsum);
+          dsum = grp16_sum(dsum);
+          if (k.c == cc) keep[e] = dsum;
+          if (FUSE && e == 0) {
+            const double dl_ = dsum + a1, du_ = a2 - dsum;
+            const double w = dl_ * fma(c1, dl_, b1) - du_ * fma(c2, du_, b2);
+#pragma unroll
+            for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[t], pc[t]);
+          }
+        }
+        if (cc == 15 || s + 1 == k.Kq) {
+          const int js = s >> 4;
+#pragma unroll
+          for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
+        }
       }
-    }
-    const int cc = s & 15;
-#pragma unroll
-    for (int e = 0; e < NVEC; ++e) {
-      double dsum = 0.0;
-#pragma unroll
-      for (int t = 0; t < T; ++t) dsum = fma(bc[t], v[e][t], dsum);
-      dsum = grp16_sum(dsum);
-      if (k.c == cc) keep[e] = dsum;
-      if (FUSE && e == 0) {
-        const double dl_ = dsum + a1, du_ = a2 - dsum;
-        const double w = dl_ * fma(c1, dl_, b1) - du_ * fma(c2, du_, b2);
-#pragma unroll
-        for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[t], pc[t]);
-      }
-    }
-    if (cc == 15 || s + 1 == k.Kq) {
-      const int js = s >> 4;
-#pragma unroll
-      for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
     }
   }
   if (FUSE) {
@@ -418,7 +445,7 @@ DEVINL int diag_factor(const Ctx& k, v4d& Ud, v4d& Yk, v4d& rk, double floor_abs
       const int kk = 4 * p + qq;
       double d = rl(Ud[p], 16 * qq + kk);
       if (!(d > floor_abs)) { if (!(fabs(d) < INFINITY)) bad = 1; d = floor_abs; }
-      const double rinv = 1.0 / sqrt(d);
+      const double rinv = rsqrt(d);
       const double f = (k.q == qq) ? rinv : 1.0;
       Ud[p] *= f; Yk[p] *= f; rk[p] *= f;
       double coef = 0.0;
@@ -648,34 +675,40 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   double* XS = ws + d.off_save;            // np
   double* LAMS = ws + d.off_save + k.np;   // rowlen
 
+  // residuals and barrier weights of one row (owner lane): everything pass 1 / pass 2 need, in owner layout
+  auto row1_body = [&](int ix, bool valid, double l, double u, double v, double tl, double tu, double zl, double zu,
+                       double& s_gap, double& m_rp) {
+    const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
+    const double rpl = hl ? v - l - tl : 0.0, rpu = hu ? u - v - tu : 0.0;
+    const double dl_ = hl ? zl / tl : 0.0, du_ = hu ? zu / tu : 0.0;
+    aRPL[ix] = rpl; aRPU[ix] = rpu;
+    rowp(k, R_CB1)[ix] = dl_; rowp(k, R_CC1)[ix] = hl ? dl_ / tl : 0.0;
+    rowp(k, R_CB2)[ix] = du_; rowp(k, R_CC2)[ix] = hu ? du_ / tu : 0.0;
+    aD[ix] = dl_ + du_;
+    aW1[ix] = -dl_ * rpl + du_ * rpu;                              // affine rhs weight
+    aW2[ix] = (hl ? 1.0 / tl : 0.0) - (hu ? 1.0 / tu : 0.0);      // centering weight (times sigma*mu)
+    aW3[ix] = (hl ? zl : 0.0) - (hu ? zu : 0.0);                  // current multiplier (for the dual residual)
+    s_gap += (hl ? tl * zl : 0.0) + (hu ? tu * zu : 0.0);
+    const double sc = fmax(1.0, fabs(v));
+    if (hl) m_rp = fmax(m_rp, fabs(rpl) / fmax(sc, fabs(l)));
+    if (hu) m_rp = fmax(m_rp, fabs(rpu) / fmax(sc, fabs(u)));
+  };
+  double gap = 0.0, rp_rel = 0.0;   // carried across iterations (produced by the update sweep)
+
   STAMP(0);
   for (it = 0; flag == 1; ++it) {
-    // ================= row phase 1: residuals, weights =================
-    double s_gap = 0, m_rp = 0;
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      const bool valid = row_valid(k, js);
-      const double l = aL[ix], u = aU[ix], v = aV[ix];
-      const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-      const double tl = aTL[ix], tu = aTU[ix], zl = aZL[ix], zu = aZU[ix];
-      const double rpl = hl ? v - l - tl : 0.0, rpu = hu ? u - v - tu : 0.0;
-      const double dl_ = hl ? zl / tl : 0.0, du_ = hu ? zu / tu : 0.0;
-      aRPL[ix] = rpl; aRPU[ix] = rpu;
-      rowp(k, R_CB1)[ix] = dl_; rowp(k, R_CC1)[ix] = hl ? dl_ / tl : 0.0;
-      rowp(k, R_CB2)[ix] = du_; rowp(k, R_CC2)[ix] = hu ? du_ / tu : 0.0;
-      aD[ix] = dl_ + du_;
-      aW1[ix] = -dl_ * rpl + du_ * rpu;                              // affine rhs weight
-      aW2[ix] = (hl ? 1.0 / tl : 0.0) - (hu ? 1.0 / tu : 0.0);      // centering weight (times sigma*mu)
-      aW3[ix] = (hl ? zl : 0.0) - (hu ? zu : 0.0);                  // current multiplier (for the dual residual)
-      s_gap += (hl ? tl * zl : 0.0) + (hu ? tu * zu : 0.0);
-      const double sc = fmax(1.0, fabs(v));
-      if (hl) m_rp = fmax(m_rp, fabs(rpl) / fmax(sc, fabs(l)));
-      if (hu) m_rp = fmax(m_rp, fabs(rpu) / fmax(sc, fabs(u)));
+    // ================= row phase 1: residuals, weights (only on entry; afterwards fused into the update sweep) =================
+    if (it == 0) {
+      double s_gap = 0, m_rp = 0;
+      for (int js = 0; js < JT; ++js) {
+        const int ix = js * 64 + lane;
+        row1_body(ix, row_valid(k, js), aL[ix], aU[ix], aV[ix], aTL[ix], aTU[ix], aZL[ix], aZU[ix], s_gap, m_rp);
+      }
+      gap = wave_sum(s_gap);
+      rp_rel = wave_max(m_rp);
+      __syncthreads();
     }
-    const double gap = wave_sum(s_gap);
     const double mu = gap / cnt;
-    const double rp_rel = wave_max(m_rp);
-    __syncthreads();
 
     STAMP(1);
     // ================= pass 1: M = H + A'DA (MFMA), p1, p2, p3; Hx =================
@@ -780,51 +813,9 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       }
     }
     STAMP(7);
-    // ================= row phase 2: affine step length, sigma, corrector weights =================
-    double a_aff = 1.0;
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      const bool valid = row_valid(k, js);
-      const double l = aL[ix], u = aU[ix];
-      const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-      const double va = aVA[ix];
-      if (hl) {
-        const double tl = aTL[ix], zl = aZL[ix], dt = va + aRPL[ix], dz = -zl - (zl / tl) * dt;
-        if (dt < 0) a_aff = fmin(a_aff, -tl / dt);
-        if (dz < 0) a_aff = fmin(a_aff, -zl / dz);
-      }
-      if (hu) {
-        const double tu = aTU[ix], zu = aZU[ix], dt = -va + aRPU[ix], dz = -zu - (zu / tu) * dt;
-        if (dt < 0) a_aff = fmin(a_aff, -tu / dt);
-        if (dz < 0) a_aff = fmin(a_aff, -zu / dz);
-      }
-    }
-    a_aff = wave_min(a_aff);
-    double s_mu_aff = 0;
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      const bool valid = row_valid(k, js);
-      const double l = aL[ix], u = aU[ix];
-      const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-      const double va = aVA[ix];
-      if (hl) {
-        const double tl = aTL[ix], zl = aZL[ix], dt = va + aRPL[ix], dz = -zl - (zl / tl) * dt;
-        s_mu_aff += (tl + a_aff * dt) * (zl + a_aff * dz);
-      }
-      if (hu) {
-        const double tu = aTU[ix], zu = aZU[ix], dt = -va + aRPU[ix], dz = -zu - (zu / tu) * dt;
-        s_mu_aff += (tu + a_aff * dt) * (zu + a_aff * dz);
-      }
-    }
-    const double mu_aff = wave_sum(s_mu_aff) / cnt;
-    double sigma = mu > 0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
-    if (sigma > 1.0) sigma = 1.0;
-    {
-      const double mu_floor = 1e-5 * P.tol * fmax(1.0, fabs(fval)) / cnt;
-      if (mu > 0 && sigma < mu_floor / mu) sigma = fmin(1.0, mu_floor / mu);
-    }
-    const double smu = sigma * mu;
-    // second-order weights: w = -(dt_a dz_a)/t per side (the sigma*mu centering part is smu * dxc)
+    // ================= row phase 2: affine step length, sigma, corrector weights (one sweep) =================
+    // mu_aff(alpha) = [S0 + alpha S1 + alpha^2 S2]/cnt with S0 = sum t z, S1 = sum (t dz + z dt), S2 = sum dt dz
+    double a_aff = 1.0, s1 = 0.0, s2 = 0.0;
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
       const bool valid = row_valid(k, js);
@@ -832,10 +823,32 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
       const double va = aVA[ix];
       double w = 0.0;
-      if (hl) { const double tl = aTL[ix], zl = aZL[ix], dt = va + aRPL[ix], dz = -zl - (zl / tl) * dt; w -= dt * dz / tl; }
-      if (hu) { const double tu = aTU[ix], zu = aZU[ix], dt = -va + aRPU[ix], dz = -zu - (zu / tu) * dt; w += dt * dz / tu; }
-      aW1[ix] = w;
+      if (hl) {
+        const double tl = aTL[ix], zl = aZL[ix], dt = va + aRPL[ix], dz = -zl - (zl / tl) * dt;
+        if (dt < 0) a_aff = fmin(a_aff, -tl / dt);
+        if (dz < 0) a_aff = fmin(a_aff, -zl / dz);
+        s1 += tl * dz + zl * dt; s2 += dt * dz;
+        w -= dt * dz / tl;
+      }
+      if (hu) {
+        const double tu = aTU[ix], zu = aZU[ix], dt = -va + aRPU[ix], dz = -zu - (zu / tu) * dt;
+        if (dt < 0) a_aff = fmin(a_aff, -tu / dt);
+        if (dz < 0) a_aff = fmin(a_aff, -zu / dz);
+        s1 += tu * dz + zu * dt; s2 += dt * dz;
+        w += dt * dz / tu;
+      }
+      if (js >= J) aW1[ix] = w;   // second-order weight of the variable-bound rows (A rows: fused in pass 2)
     }
+    a_aff = wave_min(a_aff);
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const double mu_aff = fmax(0.0, gap + a_aff * (s1 + a_aff * s2)) / cnt;
+    double sigma = mu > 0 ? (mu_aff / mu) * (mu_aff / mu) * (mu_aff / mu) : 0.0;
+    if (sigma > 1.0) sigma = 1.0;
+    {
+      const double mu_floor = 1e-5 * P.tol * fmax(1.0, fabs(fval)) / cnt;
+      if (mu > 0 && sigma < mu_floor / mu) sigma = fmin(1.0, mu_floor / mu);
+    }
+    const double smu = sigma * mu;
     __syncthreads();
     STAMP(8);
     // ================= corrector: P1 = A' w_cor came out of the fused pass 2 =================
@@ -866,7 +879,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       if (i < n) DX[i] = R1[i] + smu * R2[i] + DX[i];
     }
     // ================= row phase 3: step length (Mehrotra heuristic on the blocking pair), update =================
-    double amax = 1e300, bp = 0, bdp = 0, bd = 0, bdd = 0;
+    double amax = 1e300, bp = 0, bdp = 0, bd = 0, bdd = 0, q1 = 0.0, q2 = 0.0;
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
       const bool valid = row_valid(k, js);
@@ -882,6 +895,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
         const double dt = dv + aRPL[ix], dz = -zl + cl / tl - (zl / tl) * dt;
         if (dt < 0 && -tl / dt < amax) { amax = -tl / dt; bp = tl; bdp = dt; bd = zl; bdd = dz; }
         if (dz < 0 && -zl / dz < amax) { amax = -zl / dz; bp = zl; bdp = dz; bd = tl; bdd = dt; }
+        q1 += tl * dz + zl * dt; q2 += dt * dz;
       }
       if (hu) {
         const double tu = aTU[ix], zu = aZU[ix];
@@ -890,6 +904,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
         const double dt = -dv + aRPU[ix], dz = -zu + cu / tu - (zu / tu) * dt;
         if (dt < 0 && -tu / dt < amax) { amax = -tu / dt; bp = tu; bdp = dt; bd = zu; bdd = dz; }
         if (dz < 0 && -zu / dz < amax) { amax = -zu / dz; bp = zu; bdp = dz; bd = tu; bdd = dt; }
+        q1 += tu * dz + zu * dt; q2 += dt * dz;
       }
     }
     const double amax_w = wave_min(amax);
@@ -899,72 +914,55 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       const unsigned long long msk = __ballot(amax == amax_w);
       const int src = __ffsll((long long)msk) - 1;
       bp = rl(bp, src); bdp = rl(bdp, src); bd = rl(bd, src); bdd = rl(bdd, src);
-      double s_full = 0;
-      for (int js = 0; js < JT; ++js) {
-        const int ix = js * 64 + lane;
-        const bool valid = row_valid(k, js);
-        const double l = aL[ix], u = aU[ix];
-        const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-        const double va = aVA[ix], dv = aVC[ix];
-        if (hl) {
-          const double tl = aTL[ix], zl = aZL[ix];
-          const double dta = va + aRPL[ix], dza = -zl - (zl / tl) * dta;
-          const double cl = smu - dta * dza;
-          const double dt = dv + aRPL[ix], dz = -zl + cl / tl - (zl / tl) * dt;
-          s_full += (tl + amax_w * dt) * (zl + amax_w * dz);
-        }
-        if (hu) {
-          const double tu = aTU[ix], zu = aZU[ix];
-          const double dta = -va + aRPU[ix], dza = -zu - (zu / tu) * dta;
-          const double cu = smu - dta * dza;
-          const double dt = -dv + aRPU[ix], dz = -zu + cu / tu - (zu / tu) * dt;
-          s_full += (tu + amax_w * dt) * (zu + amax_w * dz);
-        }
-      }
+      q1 = wave_sum(q1); q2 = wave_sum(q2);
       const double gamma_f = 0.99, gamma_a = 1.0 / (1.0 - gamma_f);
-      const double mufull = wave_sum(s_full) / cnt / gamma_a;
+      const double mufull = fmax(0.0, gap + amax_w * (q1 + amax_w * q2)) / cnt / gamma_a;
       const double a_h = (-bp + mufull / (bd + amax_w * bdd)) / bdp;
       alpha = fmin(1.0, fmin(0.99999999 * amax_w, fmax(a_h, gamma_f * amax_w)));
     }
-    // update
+    // update, fused with the residual / weight phase of the next iteration
+    double xn = 0, zn = 0, s_gap = 0, m_rp = 0;
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
       const bool valid = row_valid(k, js);
       const double l = aL[ix], u = aU[ix];
       const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
       const double va = aVA[ix], dv = aVC[ix];
+      double tl = aTL[ix], zl = aZL[ix], tu = aTU[ix], zu = aZU[ix];
       if (hl) {
-        const double tl = aTL[ix], zl = aZL[ix];
         const double dta = va + aRPL[ix], dza = -zl - (zl / tl) * dta;
         const double cl = smu - dta * dza;
         const double dt = dv + aRPL[ix], dz = -zl + cl / tl - (zl / tl) * dt;
-        aTL[ix] = tl + alpha * dt; aZL[ix] = zl + alpha * dz;
+        tl += alpha * dt; zl += alpha * dz;
+        aTL[ix] = tl; aZL[ix] = zl;
+        zn = fmax(zn, zl);
       }
       if (hu) {
-        const double tu = aTU[ix], zu = aZU[ix];
         const double dta = -va + aRPU[ix], dza = -zu - (zu / tu) * dta;
         const double cu = smu - dta * dza;
         const double dt = -dv + aRPU[ix], dz = -zu + cu / tu - (zu / tu) * dt;
-        aTU[ix] = tu + alpha * dt; aZU[ix] = zu + alpha * dz;
+        tu += alpha * dt; zu += alpha * dz;
+        aTU[ix] = tu; aZU[ix] = zu;
+        zn = fmax(zn, zu);
       }
-      aV[ix] = aV[ix] + alpha * dv;
+      const double v = aV[ix] + alpha * dv;
+      aV[ix] = v;
+      row1_body(ix, valid, l, u, v, tl, tu, zl, zu, s_gap, m_rp);
     }
-    double xn = 0, zn = 0;
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
       if (i < n) { X[i] += alpha * DX[i]; xn = fmax(xn, fabs(X[i])); }
     }
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      if (row_valid(k, js)) zn = fmax(zn, fmax(aL[ix] > -INFINITY ? aZL[ix] : 0.0, aU[ix] < INFINITY ? aZU[ix] : 0.0));
-    }
+    const double rp_prev = rp_rel;
+    gap = wave_sum(s_gap);
+    rp_rel = wave_max(m_rp);
     xn = wave_max(xn); zn = wave_max(zn);
     __syncthreads();
     STAMP(12);
     // divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47)
     if (xn > 1e13) { flag = -3; break; }
-    if (zn > 1e15 && rp_rel > 1e-6) { flag = -2; break; }
-    if (stall > 25) { flag = rp_rel > 1e-6 ? -2 : (have_saved ? 2 : 1); break; }
+    if (zn > 1e15 && rp_prev > 1e-6) { flag = -2; break; }
+    if (stall > 25) { flag = rp_prev > 1e-6 ? -2 : (have_saved ? 2 : 1); break; }
   }
 
   // ---- outputs ----
