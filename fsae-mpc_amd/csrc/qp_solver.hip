@@ -33,6 +33,27 @@ DEVINL double rl(double v, int src) {  // wave-uniform broadcast of lane `src` (
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+template <int CTRL> DEVINL double dpp_f64(double v) {  // data-parallel-primitive lane move of both halves (VALU speed, no LDS)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+DEVINL double grp16_sum(double v) {  // sum over the 16 lanes sharing l>>4 (one DPP row); every lane gets the total
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  return v;
+}
+DEVINL double grp16_max(double v) {
+  v = fmax(v, dpp_f64<0xB1>(v)); v = fmax(v, dpp_f64<0x4E>(v)); v = fmax(v, dpp_f64<0x141>(v)); v = fmax(v, dpp_f64<0x140>(v));
+  return v;
+}
+DEVINL double grp16_min(double v) {
+  v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0x140>(v));
+  return v;
+}
+// whole-wave reductions: DPP within the four 16-lane rows, then four scalar lane reads (no LDS round trips)
 DEVINL double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
@@ -46,18 +67,6 @@ DEVINL double wave_max(double v) {
 DEVINL double wave_min(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return v;
-}
-template <int CTRL> DEVINL double dpp_f64(double v) {  // data-parallel-primitive lane move of both halves (VALU speed, no LDS)
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-DEVINL double grp16_sum(double v) {  // sum over the 16 lanes sharing l>>4 (one DPP row); every lane gets the total
-  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_f64<0x141>(v);   // row_half_mirror
-  v += dpp_f64<0x140>(v);   // row_mirror
   return v;
 }
 DEVINL double q_sum(double v) {  // sum over the 4 lane groups (same l&15)
@@ -202,7 +211,8 @@ DEVINL bool row_valid(const Ctx& k, int js) {
   return (js - k.J) * 64 + k.lane < k.n;
 }
 
-// Hx through the full symmetric tile grid; the loads of tile row I+1 are in flight while row I is consumed
+// Hx through the full symmetric tile grid; the loads of tile row I+1 are in flight while row I is consumed.
+// (Fusing this with the accumulator initialisation was measured 5x slower: the unrolled form spills.)
 template <int T> DEVINL void hx_tiles(const Ctx& k, const double* X, double* HX) {
   double hx[T], hn[T][4], hc[T][4];
 #pragma unroll
@@ -432,6 +442,24 @@ DEVINL v4d tile_transpose(const Ctx& k, double* scratch, const v4d& Xt) {
   return Z;
 }
 
+// resident LDS tiles (row-major, 17-double rows): store once, read back either as stored or transposed
+DEVINL void tile_store(const Ctx& k, double* slot, const v4d& Xt) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) slot[(k.q + 4 * p) * 17 + k.c] = Xt[p];
+}
+DEVINL v4d tile_load(const Ctx& k, const double* slot) {
+  v4d Z;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) Z[p] = slot[(k.q + 4 * p) * 17 + k.c];
+  return Z;
+}
+DEVINL v4d tile_load_t(const Ctx& k, const double* slot) {
+  v4d Z;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) Z[p] = slot[k.c * 17 + k.q + 4 * p];
+  return Z;
+}
+
 // Factorise one 16x16 diagonal tile D = U'U in place by 16 row steps (4 panels x 4 rows; the rows of later panels
 // are updated by one K=4 MFMA per panel) and apply the same row operations to two companion tiles: Yk (enters as
 // the identity, leaves as U^-T) and the right-hand-side tile rk (leaves as U^-T rk).  Only these three tiles see
@@ -469,13 +497,14 @@ DEVINL int diag_factor(const Ctx& k, v4d& Ud, v4d& Yk, v4d& rk, double floor_abs
 // Blocked Cholesky of acc (upper tiles) in place.  Yt[K] = U_KK^-T and Wt[K] = U_KK^-1 are kept for the solves;
 // rh rides along and leaves as y = U^-T b.
 template <int T, int K> struct FactorStep {
-  static DEVINL int run(const Ctx& k, v4d* acc, v4d* Yt, v4d* Wt, v4d* rh, double* scratch, double floor_abs) {
+  static DEVINL int run(const Ctx& k, v4d* acc, double* YL, v4d* rh, double floor_abs) {
     v4d Yk;
 #pragma unroll
     for (int p = 0; p < 4; ++p) Yk[p] = (k.q + 4 * p == k.c) ? 1.0 : 0.0;
     int bad = diag_factor(k, acc[Tri<T>::idx(K, K)], Yk, rh[K], floor_abs);
-    const v4d Wk = tile_transpose(k, scratch, Yk);
-    Yt[K] = Yk; Wt[K] = Wk;
+    tile_store(k, YL + K * 272, Yk);          // U_KK^-T stays in LDS for the solves of this iteration
+    __syncthreads();
+    const v4d Wk = tile_load_t(k, YL + K * 272);   // U_KK^-1
 #pragma unroll
     for (int Jt = K + 1; Jt < T; ++Jt) acc[Tri<T>::idx(K, Jt)] = mfma4_new(Wk, acc[Tri<T>::idx(K, Jt)]);   // U_KJ = U_KK^-T M_KJ
 #pragma unroll
@@ -485,28 +514,28 @@ template <int T, int K> struct FactorStep {
       for (int Jt = I; Jt < T; ++Jt) mfma4_sub<T>(UKI, acc[Tri<T>::idx(K, Jt)], acc[Tri<T>::idx(I, Jt)]);
       mfma4_sub<T>(UKI, rh[K], rh[I]);
     }
-    return bad | FactorStep<T, K + 1>::run(k, acc, Yt, Wt, rh, scratch, floor_abs);
+    return bad | FactorStep<T, K + 1>::run(k, acc, YL, rh, floor_abs);
   }
 };
 template <int T> struct FactorStep<T, T> {
-  static DEVINL int run(const Ctx&, v4d*, v4d*, v4d*, v4d*, double*, double) { return 0; }
+  static DEVINL int run(const Ctx&, v4d*, double*, v4d*, double) { return 0; }
 };
-template <int T> DEVINL int reg_factor(const Ctx& k, v4d* acc, v4d* Yt, v4d* Wt, v4d* rh, double* scratch, double floor_abs) {
-  return FactorStep<T, 0>::run(k, acc, Yt, Wt, rh, scratch, floor_abs);
+template <int T> DEVINL int reg_factor(const Ctx& k, v4d* acc, double* YL, v4d* rh, double floor_abs) {
+  return FactorStep<T, 0>::run(k, acc, YL, rh, floor_abs);
 }
 
 // forward solve U'y = b on a fresh right-hand-side tile column: y_K = U_KK^-T (b_K - sum_{I<K} U_IK' y_I)
-template <int T> DEVINL void reg_forward(const Ctx& k, const v4d* acc, const v4d* Wt, v4d* rh) {
+template <int T> DEVINL void reg_forward(const Ctx& k, const v4d* acc, const double* YL, v4d* rh) {
 #pragma unroll
   for (int K = 0; K < T; ++K) {
-    rh[K] = mfma4_new(Wt[K], rh[K]);
+    rh[K] = mfma4_new(tile_load_t(k, YL + K * 272), rh[K]);
 #pragma unroll
     for (int I = K + 1; I < T; ++I) mfma4_sub<T>(acc[Tri<T>::idx(K, I)], rh[K], rh[I]);
   }
 }
 
 // backward solve U x = y in place: x_K = U_KK^-1 (y_K - sum_{J>K} U_KJ x_J); U_KJ' comes through the LDS scratch
-template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const v4d* Yt, v4d* rh, double* scratch) {
+template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const double* YL, v4d* rh, double* scratch) {
 #pragma unroll
   for (int K = T - 1; K >= 0; --K) {
 #pragma unroll
@@ -514,7 +543,7 @@ template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const v4
       const v4d Lt = tile_transpose(k, scratch, acc[Tri<T>::idx(K, Jt)]);   // Lt[kappa][i] = U_KJ[i][kappa]
       mfma4_sub<T>(Lt, rh[Jt], rh[K]);
     }
-    rh[K] = mfma4_new(Yt[K], rh[K]);                                         // (U_KK^-T)' = U_KK^-1
+    rh[K] = mfma4_new(tile_load(k, YL + K * 272), rh[K]);                    // (U_KK^-T)' = U_KK^-1
   }
 }
 
@@ -567,6 +596,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
   double* SCR = lds + (size_t)V_NARR * d.np;   // 16 x 17 tile-transpose scratch
+  double* YL = SCR + 16 * 17 + 16;              // T resident tiles U_KK^-T
   const double* gw = ws + d.off_gw;
   const double* Es = ws + d.off_E;
   const double* Fs = ws + d.off_F;
@@ -693,6 +723,16 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     if (hl) m_rp = fmax(m_rp, fabs(rpl) / fmax(sc, fabs(l)));
     if (hu) m_rp = fmax(m_rp, fabs(rpu) / fmax(sc, fabs(u)));
   };
+  struct Slot { int ix; bool valid; double l, u, v, tl, tu, zl, zu, va, vc, w2, rpl, rpu; };
+  auto load_slot = [&](int js) {   // all loads of one owner-layout slot, issued together (one latency per trip)
+    Slot s_;
+    const int jc = js < JT ? js : JT - 1;
+    s_.ix = jc * 64 + lane; s_.valid = js < JT && row_valid(k, jc);
+    const int ix = s_.ix;
+    s_.l = aL[ix]; s_.u = aU[ix]; s_.v = aV[ix]; s_.tl = aTL[ix]; s_.tu = aTU[ix]; s_.zl = aZL[ix]; s_.zu = aZU[ix];
+    s_.va = aVA[ix]; s_.vc = aVC[ix]; s_.w2 = aW2[ix]; s_.rpl = aRPL[ix]; s_.rpu = aRPU[ix];
+    return s_;
+  };
   double gap = 0.0, rp_rel = 0.0;   // carried across iterations (produced by the update sweep)
 
   STAMP(0);
@@ -780,11 +820,11 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
     }
     STAMP(4);
-    v4d rh[T], Yt[T], Wt[T];
+    v4d rh[T];
     rhs_load<T>(k, rh, R1, R2);
-    if (reg_factor<T>(k, acc, Yt, Wt, rh, SCR, 1e-30 * dmax)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
+    if (reg_factor<T>(k, acc, YL, rh, 1e-30 * dmax)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
     STAMP(5);
-    reg_backward<T>(k, acc, Yt, rh, SCR);
+    reg_backward<T>(k, acc, YL, rh, SCR);
     rhs_store<T>(k, rh, R1, R2);
     __syncthreads();
     STAMP(6);
@@ -816,28 +856,28 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     // ================= row phase 2: affine step length, sigma, corrector weights (one sweep) =================
     // mu_aff(alpha) = [S0 + alpha S1 + alpha^2 S2]/cnt with S0 = sum t z, S1 = sum (t dz + z dt), S2 = sum dt dz
     double a_aff = 1.0, s1 = 0.0, s2 = 0.0;
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      const bool valid = row_valid(k, js);
-      const double l = aL[ix], u = aU[ix];
-      const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-      const double va = aVA[ix];
+    auto row2_body = [&](const Slot& r, int js) {
+      const bool hl = r.valid && r.l > -INFINITY, hu = r.valid && r.u < INFINITY;
       double w = 0.0;
       if (hl) {
-        const double tl = aTL[ix], zl = aZL[ix], dt = va + aRPL[ix], dz = -zl - (zl / tl) * dt;
-        if (dt < 0) a_aff = fmin(a_aff, -tl / dt);
-        if (dz < 0) a_aff = fmin(a_aff, -zl / dz);
-        s1 += tl * dz + zl * dt; s2 += dt * dz;
-        w -= dt * dz / tl;
+        const double dt = r.va + r.rpl, dz = -r.zl - (r.zl / r.tl) * dt;
+        if (dt < 0) a_aff = fmin(a_aff, -r.tl / dt);
+        if (dz < 0) a_aff = fmin(a_aff, -r.zl / dz);
+        s1 += r.tl * dz + r.zl * dt; s2 += dt * dz;
+        w -= dt * dz / r.tl;
       }
       if (hu) {
-        const double tu = aTU[ix], zu = aZU[ix], dt = -va + aRPU[ix], dz = -zu - (zu / tu) * dt;
-        if (dt < 0) a_aff = fmin(a_aff, -tu / dt);
-        if (dz < 0) a_aff = fmin(a_aff, -zu / dz);
-        s1 += tu * dz + zu * dt; s2 += dt * dz;
-        w += dt * dz / tu;
+        const double dt = -r.va + r.rpu, dz = -r.zu - (r.zu / r.tu) * dt;
+        if (dt < 0) a_aff = fmin(a_aff, -r.tu / dt);
+        if (dz < 0) a_aff = fmin(a_aff, -r.zu / dz);
+        s1 += r.tu * dz + r.zu * dt; s2 += dt * dz;
+        w += dt * dz / r.tu;
       }
-      if (js >= J) aW1[ix] = w;   // second-order weight of the variable-bound rows (A rows: fused in pass 2)
+      if (js >= J && js < JT) aW1[r.ix] = w;   // second-order weight of the variable-bound rows (A rows: fused in pass 2)
+    };
+    for (int js = 0; js < JT; js += 2) {
+      const Slot r0 = load_slot(js), r1 = load_slot(js + 1);
+      row2_body(r0, js); row2_body(r1, js + 1);
     }
     a_aff = wave_min(a_aff);
     s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -860,8 +900,8 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     __syncthreads();
     {
       rhs_load<T>(k, rh, DX, nullptr);
-      reg_forward<T>(k, acc, Wt, rh);
-      reg_backward<T>(k, acc, Yt, rh, SCR);
+      reg_forward<T>(k, acc, YL, rh);
+      reg_backward<T>(k, acc, YL, rh, SCR);
       rhs_store<T>(k, rh, DX, nullptr);
     }
     __syncthreads();
@@ -880,32 +920,30 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     }
     // ================= row phase 3: step length (Mehrotra heuristic on the blocking pair), update =================
     double amax = 1e300, bp = 0, bdp = 0, bd = 0, bdd = 0, q1 = 0.0, q2 = 0.0;
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      const bool valid = row_valid(k, js);
-      const double l = aL[ix], u = aU[ix];
-      const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-      const double va = aVA[ix];
-      const double dv = va + smu * aVC[ix] + aW2[ix];
-      aVC[ix] = dv;  // keep the full G dx for the update
+    auto row3a_body = [&](const Slot& r, int js) {
+      const bool hl = r.valid && r.l > -INFINITY, hu = r.valid && r.u < INFINITY;
+      const double dv = r.va + smu * r.vc + r.w2;
+      if (js < JT) aVC[r.ix] = dv;  // keep the full G dx for the update
       if (hl) {
-        const double tl = aTL[ix], zl = aZL[ix];
-        const double dta = va + aRPL[ix], dza = -zl - (zl / tl) * dta;
+        const double dta = r.va + r.rpl, dza = -r.zl - (r.zl / r.tl) * dta;
         const double cl = smu - dta * dza;
-        const double dt = dv + aRPL[ix], dz = -zl + cl / tl - (zl / tl) * dt;
-        if (dt < 0 && -tl / dt < amax) { amax = -tl / dt; bp = tl; bdp = dt; bd = zl; bdd = dz; }
-        if (dz < 0 && -zl / dz < amax) { amax = -zl / dz; bp = zl; bdp = dz; bd = tl; bdd = dt; }
-        q1 += tl * dz + zl * dt; q2 += dt * dz;
+        const double dt = dv + r.rpl, dz = -r.zl + cl / r.tl - (r.zl / r.tl) * dt;
+        if (dt < 0 && -r.tl / dt < amax) { amax = -r.tl / dt; bp = r.tl; bdp = dt; bd = r.zl; bdd = dz; }
+        if (dz < 0 && -r.zl / dz < amax) { amax = -r.zl / dz; bp = r.zl; bdp = dz; bd = r.tl; bdd = dt; }
+        q1 += r.tl * dz + r.zl * dt; q2 += dt * dz;
       }
       if (hu) {
-        const double tu = aTU[ix], zu = aZU[ix];
-        const double dta = -va + aRPU[ix], dza = -zu - (zu / tu) * dta;
+        const double dta = -r.va + r.rpu, dza = -r.zu - (r.zu / r.tu) * dta;
         const double cu = smu - dta * dza;
-        const double dt = -dv + aRPU[ix], dz = -zu + cu / tu - (zu / tu) * dt;
-        if (dt < 0 && -tu / dt < amax) { amax = -tu / dt; bp = tu; bdp = dt; bd = zu; bdd = dz; }
-        if (dz < 0 && -zu / dz < amax) { amax = -zu / dz; bp = zu; bdp = dz; bd = tu; bdd = dt; }
-        q1 += tu * dz + zu * dt; q2 += dt * dz;
+        const double dt = -dv + r.rpu, dz = -r.zu + cu / r.tu - (r.zu / r.tu) * dt;
+        if (dt < 0 && -r.tu / dt < amax) { amax = -r.tu / dt; bp = r.tu; bdp = dt; bd = r.zu; bdd = dz; }
+        if (dz < 0 && -r.zu / dz < amax) { amax = -r.zu / dz; bp = r.zu; bdp = dz; bd = r.tu; bdd = dt; }
+        q1 += r.tu * dz + r.zu * dt; q2 += dt * dz;
       }
+    };
+    for (int js = 0; js < JT; js += 2) {
+      const Slot r0 = load_slot(js), r1 = load_slot(js + 1);
+      row3a_body(r0, js); row3a_body(r1, js + 1);
     }
     const double amax_w = wave_min(amax);
     double alpha = 1.0;
@@ -922,32 +960,34 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     }
     // update, fused with the residual / weight phase of the next iteration
     double xn = 0, zn = 0, s_gap = 0, m_rp = 0;
-    for (int js = 0; js < JT; ++js) {
-      const int ix = js * 64 + lane;
-      const bool valid = row_valid(k, js);
-      const double l = aL[ix], u = aU[ix];
-      const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-      const double va = aVA[ix], dv = aVC[ix];
-      double tl = aTL[ix], zl = aZL[ix], tu = aTU[ix], zu = aZU[ix];
+    auto row3b_body = [&](const Slot& r, int js) {
+      if (js >= JT) return;
+      const bool hl = r.valid && r.l > -INFINITY, hu = r.valid && r.u < INFINITY;
+      const double dv = r.vc;   // full G dx stored by the previous sweep
+      double tl = r.tl, zl = r.zl, tu = r.tu, zu = r.zu;
       if (hl) {
-        const double dta = va + aRPL[ix], dza = -zl - (zl / tl) * dta;
+        const double dta = r.va + r.rpl, dza = -zl - (zl / tl) * dta;
         const double cl = smu - dta * dza;
-        const double dt = dv + aRPL[ix], dz = -zl + cl / tl - (zl / tl) * dt;
+        const double dt = dv + r.rpl, dz = -zl + cl / tl - (zl / tl) * dt;
         tl += alpha * dt; zl += alpha * dz;
-        aTL[ix] = tl; aZL[ix] = zl;
+        aTL[r.ix] = tl; aZL[r.ix] = zl;
         zn = fmax(zn, zl);
       }
       if (hu) {
-        const double dta = -va + aRPU[ix], dza = -zu - (zu / tu) * dta;
+        const double dta = -r.va + r.rpu, dza = -zu - (zu / tu) * dta;
         const double cu = smu - dta * dza;
-        const double dt = -dv + aRPU[ix], dz = -zu + cu / tu - (zu / tu) * dt;
+        const double dt = -dv + r.rpu, dz = -zu + cu / tu - (zu / tu) * dt;
         tu += alpha * dt; zu += alpha * dz;
-        aTU[ix] = tu; aZU[ix] = zu;
+        aTU[r.ix] = tu; aZU[r.ix] = zu;
         zn = fmax(zn, zu);
       }
-      const double v = aV[ix] + alpha * dv;
-      aV[ix] = v;
-      row1_body(ix, valid, l, u, v, tl, tu, zl, zu, s_gap, m_rp);
+      const double v = r.v + alpha * dv;
+      aV[r.ix] = v;
+      row1_body(r.ix, r.valid, r.l, r.u, v, tl, tu, zl, zu, s_gap, m_rp);
+    };
+    for (int js = 0; js < JT; js += 2) {
+      const Slot r0 = load_slot(js), r1 = load_slot(js + 1);
+      row3b_body(r0, js); row3b_body(r1, js + 1);
     }
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
@@ -1073,7 +1113,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->off_save = off; off += d->np + d->rowlen;
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
-  d->lds_solve = ((size_t)V_NARR * d->np + 16 * 17 + 16) * sizeof(double);
+  d->lds_solve = ((size_t)V_NARR * d->np + 16 * 17 + 16 + (size_t)d->T * 272) * sizeof(double);
   d->lds_prep = ((size_t)d->np + 16 * (size_t)(4 * d->Kq + 1)) * sizeof(double);
 }
 
