@@ -1002,7 +1002,9 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     // divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47)
     if (xn > 1e13) { flag = -3; break; }
     if (zn > 1e15 && rp_prev > 1e-6) { flag = -2; break; }
-    if (stall > 25) { flag = rp_prev > 1e-6 ? -2 : (have_saved ? 2 : 1); break; }
+    // once an iterate met tol_loose, a handful of non-improving iterations means the end game lost its numerical
+    // footing: return the saved iterate (this also bounds the iteration tail, i.e. the kernel's drain time)
+    if (stall > (have_saved ? 5 : 25)) { flag = have_saved ? 2 : (rp_prev > 1e-6 ? -2 : 1); break; }
   }
 
   // ---- outputs ----

@@ -509,7 +509,9 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
     for (int i = 0; i < mt; ++i) zn = fmax(zn, fmax(w.hl[i] ? zl[i] : 0, w.hu[i] ? zu[i] : 0));
     if (xn > 1e13) { flag = -3; break; }
     if (zn > 1e15 && rp_rel > 1e-6) { flag = -2; break; }
-    if (stall > 25) { flag = rp_rel > 1e-6 ? -2 : 1; break; }
+    /* once an iterate met tol_loose, a handful of non-improving iterations means the end game has lost its
+     * numerical footing: stop early and return the saved iterate (bounds the iteration tail of a batch) */
+    if (stall > (have_saved ? 5 : 25)) { flag = rp_rel > 1e-6 && !have_saved ? -2 : 1; break; }
   }
 
 finish:
