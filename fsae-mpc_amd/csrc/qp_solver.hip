@@ -85,7 +85,7 @@ template <int T> struct Tri {
 __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
   const int b = blockIdx.x, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
   const QpDims& d = P.d;
-  const int n = d.n, m = d.m, T = d.T, Kq = d.Kq, J = d.J, JB = d.JB, np = d.np;
+  const int n = d.n, m = d.m, T = d.T, Kq = d.Kq, J = d.J, JB = d.JB, np = d.np, nc = d.nc, nb = d.nb;
   const double* H = P.H + (P.shared_HA ? 0 : (size_t)b * n * n);
   const double* A = P.A + (P.shared_HA ? 0 : (size_t)b * m * n);
   const double* g = P.g + (size_t)b * n;
@@ -95,6 +95,8 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
   double* gw = ws + d.off_gw;
   double* Es = ws + d.off_E;
   double* Fs = ws + d.off_F;   // owner layout, J slots
+  double* Ab = ws + d.off_Ab;  // 4 border columns of A~, owner layout
+  double* Hb = ws + d.off_Hb;  // 4 border columns of H~ (full length np)
   double* Lr = ws + d.off_rows + 0 * (size_t)d.rowlen;  // scaled lower bounds (owner layout, rows then vars)
   double* Ur = ws + d.off_rows + 1 * (size_t)d.rowlen;
   extern __shared__ double lds[];
@@ -133,6 +135,8 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
       for (int j = 0; j < n; ++j) rm = fmax(rm, fabs(A[(size_t)j * m + r]) * Esh[j]);
     double f = (valid && rm > 1e-12) ? 1.0 / rm : (valid ? 1.0 : 0.0);
     Fs[js * 64 + lane] = f;
+    for (int bb = 0; bb < 4; ++bb)
+      Ab[(size_t)bb * J * 64 + js * 64 + lane] = (valid && bb < nb) ? A[(size_t)(nc + bb) * m + r] * Esh[nc + bb] * f : 0.0;
     double l = -INFINITY, u = INFINITY;
     if (valid) {
       double lr = P.lbA[(size_t)b * m + r], ur = P.ubA[(size_t)b * m + r];
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
         // LDS index space is (q*Kq + s) = position in the permuted K order; r here is that position
         const int qq = r / Kq, ss = r - qq * Kq;
         const int row = qq * Kq + ss;  // == r (rows are laid out contiguously per lane group)
-        if (col < n && row < m) v = A[(size_t)col * m + row] * Esh[col];
+        if (col < nc && col < n && row < m) v = A[(size_t)col * m + row] * Esh[col];
         tile[cc * mp1 + r] = v;
       }
     }
@@ -184,24 +188,27 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
       for (int p = 0; p < 4; ++p) {
         const int row = 16 * I + q + 4 * p, col = 16 * Jt + c;
         double v = 0.0;
-        if (row < n && col < n) v = H[(size_t)row * n + col] * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
+        if (row < nc && col < nc && row < n && col < n) v = H[(size_t)row * n + col] * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
         Hw[((size_t)(I * T + Jt) * 4 + p) * 64 + lane] = v;
       }
+  for (int bb = 0; bb < 4; ++bb)
+    for (int i = lane; i < np; i += 64)
+      Hb[(size_t)bb * np + i] = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // solve kernel
 // ---------------------------------------------------------------------------------------------
 struct Ctx {
-  int n, m, T, Kq, J, JB, JT, np, ld, lane, c, q;
-  const double* Aw; const double* Hw;
+  int n, m, T, Kq, J, JB, JT, np, ld, lane, c, q, nc, nb;
+  const double* Aw; const double* Hw; const double* Ab; const double* Hb;
   double* rows;  // base of owner-layout row arrays
   int rowlen;
   double* Ms;    // LDS n x ld
   double* vec;   // LDS n-vectors, np each
 };
 enum RowArr { R_L = 0, R_U, R_TL, R_TU, R_ZL, R_ZU, R_V, R_D, R_W1, R_W2, R_W3, R_VA, R_VC, R_RPL, R_RPU, R_CB1, R_CC1, R_CB2, R_CC2, R_NARR };
-enum VecArr { V_X = 0, V_G, V_HX, V_R1, V_R2, V_P1, V_P2, V_P3, V_DX, V_E, V_NARR };
+enum VecArr { V_X = 0, V_G, V_HX, V_R1, V_R2, V_P1, V_P2, V_P3, V_DX, V_E, V_NARR };   // + 4 border-column vectors MB[b] behind them
 
 DEVINL double* rowp(const Ctx& k, int arr) { return k.rows + (size_t)arr * k.rowlen; }
 DEVINL double* vecp(const Ctx& k, int arr) { return k.vec + arr * k.np; }
@@ -264,35 +271,49 @@ template <int T> DEVINL void acc_init(const Ctx& k, v4d* acc) {
 // pass 1: acc += A~' D A~ on the matrix cores; p1 = A~'w1, p2 = A~'w2, p3 = A~'w3 on the VALU beside them.
 // A ring of PF k-steps of operands is kept in flight (L2 / Infinity-Cache latency under load is ~2-3k cycles,
 // one k-step of MFMA work is ~1.3k cycles).
-template <int T> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, double* P2, double* P3) {
+template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, double* P2, double* P3, double* MB) {
   constexpr int PF = 3;
+  constexpr int NBB = NB > 0 ? NB : 1;
   const double* D = rowp(k, R_D); const double* W1 = rowp(k, R_W1);
   const double* W2 = rowp(k, R_W2); const double* W3 = rowp(k, R_W3);
-  double p1[T], p2[T], p3[T], bq[PF][T], cq[PF][4];
+  const int JS = k.J * 64;
+  double p1[T], p2[T], p3[T], bq[PF][T], cq[PF][4 + NBB];
+  double pb[NBB][T], sbb[NBB][NBB], pwb[3][NBB];   // border: column of A'DA, border block, border entries of p1..p3
 #pragma unroll
   for (int t = 0; t < T; ++t) { p1[t] = 0; p2[t] = 0; p3[t] = 0; }
+#pragma unroll
+  for (int e = 0; e < NBB; ++e) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) pb[e][t] = 0;
+#pragma unroll
+    for (int f = 0; f < NBB; ++f) sbb[e][f] = 0;
+    pwb[0][e] = pwb[1][e] = pwb[2][e] = 0;
+  }
   auto issue = [&](int u, int s) {
 #pragma unroll
     for (int t = 0; t < T; ++t) bq[u][t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
     const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
     cq[u][0] = D[ri]; cq[u][1] = W1[ri]; cq[u][2] = W2[ri]; cq[u][3] = W3[ri];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) cq[u][4 + e] = k.Ab[(size_t)e * JS + ri];
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
-    if (u < k.Kq) issue(u, u);
-    else {
 #pragma unroll
-      for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
-      cq[u][0] = cq[u][1] = cq[u][2] = cq[u][3] = 0.0;
-    }
+    for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4 + NBB; ++e) cq[u][e] = 0.0;
+    if (u < k.Kq) issue(u, u);
   }
   for (int s0 = 0; s0 < k.Kq; s0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int s = s0 + u;
       if (s < k.Kq) {
-        double bc[T], a[T];
+        double bc[T], a[T], ab[NBB];
         const double dd = cq[u][0], w1 = cq[u][1], w2 = cq[u][2], w3 = cq[u][3];
+#pragma unroll
+        for (int e = 0; e < NB; ++e) ab[e] = cq[u][4 + e];
 #pragma unroll
         for (int t = 0; t < T; ++t) { bc[t] = bq[u][t]; a[t] = dd * bc[t]; }
         if (s + PF < k.Kq) issue(u, s + PF);
@@ -305,6 +326,15 @@ template <int T> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, doubl
         for (int t = 0; t < T; ++t) {
           p1[t] = fma(w1, bc[t], p1[t]); p2[t] = fma(w2, bc[t], p2[t]); p3[t] = fma(w3, bc[t], p3[t]);
         }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+          const double dab = dd * ab[e];
+#pragma unroll
+          for (int t = 0; t < T; ++t) pb[e][t] = fma(dab, bc[t], pb[e][t]);
+#pragma unroll
+          for (int f = e; f < NB; ++f) sbb[e][f] = fma(dab, ab[f], sbb[e][f]);
+          pwb[0][e] = fma(w1, ab[e], pwb[0][e]); pwb[1][e] = fma(w2, ab[e], pwb[1][e]); pwb[2][e] = fma(w3, ab[e], pwb[2][e]);
+        }
       }
     }
   }
@@ -313,37 +343,57 @@ template <int T> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, doubl
     double v1 = q_sum(p1[t]), v2 = q_sum(p2[t]), v3 = q_sum(p3[t]);
     if (k.q == 0) { P1[16 * t + k.c] = v1; P2[16 * t + k.c] = v2; P3[16 * t + k.c] = v3; }
   }
+#pragma unroll
+  for (int e = 0; e < NB; ++e) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) { const double vb = q_sum(pb[e][t]); if (k.q == 0) MB[e * k.np + 16 * t + k.c] = vb; }
+    // border scalars are identical on the 16 lanes of a group: sum the four groups, lane 0 writes
+    const double v1 = q_sum(pwb[0][e]), v2 = q_sum(pwb[1][e]), v3 = q_sum(pwb[2][e]);
+    if (k.lane == 0) { P1[k.nc + e] = v1; P2[k.nc + e] = v2; P3[k.nc + e] = v3; }
+#pragma unroll
+    for (int f = 0; f < NB; ++f) {
+      const double sv = q_sum(f >= e ? sbb[e][f] : sbb[f][e]);
+      if (k.lane == 0) MB[e * k.np + k.nc + f] = sv;
+    }
+  }
 }
 
 // y = A~ v for NVEC vectors (LDS n-vectors) -> owner-layout row arrays.  FUSE: the first vector is the affine
 // direction; as soon as a row's va = a_r' dxa is reduced, the second-order weight
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
-template <int T, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor) {
+template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor) {
   constexpr int PF = 4;   // k-steps of operands in flight (little compute per step => latency bound otherwise)
-  double v[NVEC][T], pc[T], bq[PF][T], cq[PF][6];
+  constexpr int NBB = NB > 0 ? NB : 1;
+  const int JS = k.J * 64;
+  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], bq[PF][T], cq[PF][6 + NBB];
 #pragma unroll
-  for (int e = 0; e < NVEC; ++e)
+  for (int e = 0; e < NVEC; ++e) {
 #pragma unroll
     for (int t = 0; t < T; ++t) v[e][t] = vin[e][16 * t + k.c];
 #pragma unroll
+    for (int f = 0; f < NB; ++f) vb[e][f] = vin[e][k.nc + f];
+  }
+#pragma unroll
   for (int t = 0; t < T; ++t) pc[t] = 0.0;
+#pragma unroll
+  for (int f = 0; f < NBB; ++f) pcb[f] = 0.0;
   const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
   const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
   auto issue = [&](int u, int s) {
 #pragma unroll
     for (int t = 0; t < T; ++t) bq[u][t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
-    if (FUSE) {
-      const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-      cq[u][0] = CA1[ri]; cq[u][1] = CB1[ri]; cq[u][2] = CC1[ri]; cq[u][3] = CA2[ri]; cq[u][4] = CB2[ri]; cq[u][5] = CC2[ri];
-    }
+    const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+    if (FUSE) { cq[u][0] = CA1[ri]; cq[u][1] = CB1[ri]; cq[u][2] = CC1[ri]; cq[u][3] = CA2[ri]; cq[u][4] = CB2[ri]; cq[u][5] = CC2[ri]; }
+#pragma unroll
+    for (int f = 0; f < NB; ++f) cq[u][6 + f] = k.Ab[(size_t)f * JS + ri];
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
 #pragma unroll
     for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
 #pragma unroll
-    for (int e = 0; e < 6; ++e) cq[u][e] = 0.0;
+    for (int e = 0; e < 6 + NBB; ++e) cq[u][e] = 0.0;
     if (u < k.Kq) issue(u, u);
   }
   double keep[NVEC];
@@ -354,8 +404,10 @@ template <int T, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const do
     for (int u = 0; u < PF; ++u) {
       const int s = s0 + u;
       if (s < k.Kq) {
-        double bc[T];
+        double bc[T], ab[NBB];
         const double a1 = cq[u][0], b1 = cq[u][1], c1 = cq[u][2], a2 = cq[u][3], b2 = cq[u][4], c2 = cq[u][5];
+#pragma unroll
+        for (int f = 0; f < NB; ++f) ab[f] = cq[u][6 + f];
 #pragma unroll
         for (int t = 0; t < T; ++t) bc[t] = bq[u][t];
         if (s + PF < k.Kq) issue(u, s + PF);
@@ -366,12 +418,16 @@ template <int T, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const do
 #pragma unroll
           for (int t = 0; t < T; ++t) dsum = fma(bc[t], v[e][t], dsum);
           dsum = grp16_sum(dsum);
+#pragma unroll
+          for (int f = 0; f < NB; ++f) dsum = fma(ab[f], vb[e][f], dsum);
           if (k.c == cc) keep[e] = dsum;
           if (FUSE && e == 0) {
             const double dl_ = dsum + a1, du_ = a2 - dsum;
             const double w = dl_ * fma(c1, dl_, b1) - du_ * fma(c2, du_, b2);
 #pragma unroll
             for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[t], pc[t]);
+#pragma unroll
+            for (int f = 0; f < NB; ++f) pcb[f] = fma(w, ab[f], pcb[f]);
           }
         }
         if (cc == 15 || s + 1 == k.Kq) {
@@ -388,24 +444,35 @@ template <int T, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const do
       double pv = q_sum(pc[t]);
       if (k.q == 0) Pcor[16 * t + k.c] = pv;
     }
+#pragma unroll
+    for (int f = 0; f < NB; ++f) { const double pv = q_sum(pcb[f]); if (k.lane == 0) Pcor[k.nc + f] = pv; }
   }
 }
 
 // p = A~' w (w: owner-layout row array) -> LDS n-vector (only used by the initial point)
-template <int T> DEVINL void pass_Atw(const Ctx& k, const double* W, double* Pout) {
-  double p[T];
+template <int T, int NB> DEVINL void pass_Atw(const Ctx& k, const double* W, double* Pout) {
+  constexpr int NBB = NB > 0 ? NB : 1;
+  const int JS = k.J * 64;
+  double p[T], pbv[NBB];
 #pragma unroll
   for (int t = 0; t < T; ++t) p[t] = 0.0;
+#pragma unroll
+  for (int f = 0; f < NBB; ++f) pbv[f] = 0.0;
   for (int s = 0; s < k.Kq; ++s) {
-    const double w = W[(s >> 4) * 64 + k.q * 16 + (s & 15)];
+    const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+    const double w = W[ri];
 #pragma unroll
     for (int t = 0; t < T; ++t) p[t] = fma(w, k.Aw[((size_t)s * T + t) * 64 + k.lane], p[t]);
+#pragma unroll
+    for (int f = 0; f < NB; ++f) pbv[f] = fma(w, k.Ab[(size_t)f * JS + ri], pbv[f]);
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     double v = q_sum(p[t]);
     if (k.q == 0) Pout[16 * t + k.c] = v;
   }
+#pragma unroll
+  for (int f = 0; f < NB; ++f) { const double pv = q_sum(pbv[f]); if (k.lane == 0) Pout[k.nc + f] = pv; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -547,27 +614,27 @@ template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const do
   }
 }
 
-// right-hand sides: LDS n-vectors -> slot `slot` of the rhs tile column, and back
-template <int T> DEVINL void rhs_load(const Ctx& k, v4d* rh, const double* v0, const double* v1) {
+// right-hand sides: NS LDS vectors <-> slots 0..NS-1 (= lane column c) of the rhs tile column (core rows only)
+template <int T, int NS> DEVINL void rhs_load(const Ctx& k, v4d* rh, const double* const* vecs) {
 #pragma unroll
   for (int K = 0; K < T; ++K)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int i = 16 * K + k.q + 4 * p;
       double v = 0.0;
-      if (k.c == 0) v = v0[i];
-      if (v1 && k.c == 1) v = v1[i];
+#pragma unroll
+      for (int e = 0; e < NS; ++e) if (k.c == e) v = vecs[e][i];
       rh[K][p] = v;
     }
 }
-template <int T> DEVINL void rhs_store(const Ctx& k, const v4d* rh, double* v0, double* v1) {
+template <int T, int NS> DEVINL void rhs_store(const Ctx& k, const v4d* rh, double* const* vecs) {
 #pragma unroll
   for (int K = 0; K < T; ++K)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int i = 16 * K + k.q + 4 * p;
-      if (k.c == 0) v0[i] = rh[K][p];
-      if (v1 && k.c == 1) v1[i] = rh[K][p];
+#pragma unroll
+      for (int e = 0; e < NS; ++e) if (k.c == e) vecs[e][i] = rh[K][p];
     }
 }
 
@@ -584,24 +651,29 @@ template <int T> DEVINL void rhs_store(const Ctx& k, const v4d* rh, double* v0, 
 #define STAMP_OUT do { } while (0)
 #endif
 
-template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams P) {
+#ifndef QP_WAVES_PER_SIMD
+#define QP_WAVES_PER_SIMD 1
+#endif
+template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void qp_solve_kernel(QpParams P) {
   const int b = blockIdx.x;
   Ctx k;
   const QpDims& d = P.d;
   k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = d.ld;
-  k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4;
+  k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
   double* ws = P.ws + (size_t)b * d.ws_per_qp;
-  k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw;
+  k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
   k.rows = ws + d.off_rows; k.rowlen = d.rowlen;
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
-  double* SCR = lds + (size_t)V_NARR * d.np;   // 16 x 17 tile-transpose scratch
+  double* MB = lds + (size_t)V_NARR * d.np;    // 4 border-column vectors (A'DA border, then U^-T m_b)
+  double* SCR = MB + (size_t)4 * d.np;          // 16 x 17 tile-transpose scratch
   double* YL = SCR + 16 * 17 + 16;              // T resident tiles U_KK^-T
   const double* gw = ws + d.off_gw;
   const double* Es = ws + d.off_E;
   const double* Fs = ws + d.off_F;
-  const int lane = k.lane, n = k.n, JT = k.JT, J = k.J;
+  const int lane = k.lane, n = k.n, JT = k.JT, J = k.J, nc = k.nc, nb = k.nb;
   constexpr int NT = Tri<T>::NT;
+  constexpr int NBB = NB > 0 ? NB : 1;
 
 #define X vecp(k, V_X)
 #define G vecp(k, V_G)
@@ -628,6 +700,28 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
 #define aVC rowp(k, R_VC)
 #define aRPL rowp(k, R_RPL)
 #define aRPU rowp(k, R_RPU)
+
+  // Hx = H~ x: core through the tile grid, border columns (full-length vectors Hb[b]) on the VALU
+  auto hx_full = [&]() {
+    hx_tiles<T>(k, X, HX);
+    if (NB > 0) {
+      __syncthreads();
+      double xb[NBB], sb[NBB];
+#pragma unroll
+      for (int e = 0; e < NB; ++e) { xb[e] = X[nc + e]; sb[e] = 0.0; }
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < n) {
+          double add = 0.0;
+#pragma unroll
+          for (int e = 0; e < NB; ++e) { const double hbi = k.Hb[(size_t)e * k.np + i]; add = fma(hbi, xb[e], add); sb[e] = fma(hbi, X[i], sb[e]); }
+          if (i < nc) HX[i] += add;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NB; ++e) { const double tot = wave_sum(sb[e]); if (lane == 0) HX[nc + e] = tot; }
+    }
+  };
 
   // ---- load n-vectors, initial x = clamp(0, l, u) (scaled), count finite sides ----
   for (int i = lane; i < k.np; i += 64) { G[i] = gw[i]; EV[i] = Es[i]; R1[i] = 0; R2[i] = 0; DX[i] = 0; }
@@ -667,7 +761,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   // ---- v = G x ----
   {
     const double* vin[1] = {X}; double* rout[1] = {aV};
-    pass_Av<T, 1, false>(k, vin, rout, nullptr);
+    pass_Av<T, NB, 1, false>(k, vin, rout, nullptr);
     for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aV[(J + jb) * 64 + lane] = i < n ? X[i] : 0.0; }
   }
   // ---- initial slacks / multipliers: t = max(resid,1), z = 1 on general rows ----
@@ -685,8 +779,8 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   __syncthreads();
   // bound multipliers absorb the initial dual residual r = Hx + g - A'(zl - zu)
   {
-    hx_tiles<T>(k, X, HX);
-    pass_Atw<T>(k, aW3, P3);
+    hx_full();
+    pass_Atw<T, NB>(k, aW3, P3);
     __syncthreads();
     for (int jb = 0; jb < k.JB; ++jb) {
       const int i = jb * 64 + lane, ix = (J + jb) * 64 + lane;
@@ -752,11 +846,11 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
 
     STAMP(1);
     // ================= pass 1: M = H + A'DA (MFMA), p1, p2, p3; Hx =================
-    hx_tiles<T>(k, X, HX);
+    hx_full();
     STAMP(2);
     v4d acc[NT];
     acc_init<T>(k, acc);
-    pass_syrk<T>(k, acc, P1, P2, P3);
+    pass_syrk<T, NB>(k, acc, P1, P2, P3, MB);
     __syncthreads();
     STAMP(3);
     // objective, dual residual
@@ -797,15 +891,21 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
       for (int p = 0; p < 4; ++p)
         if (mine && p == (k.c >> 2)) { acc[Tri<T>::idx(K, K)][p] += dadd; dmax_l = fmax(dmax_l, acc[Tri<T>::idx(K, K)][p]); }
     }
-    const double dmax = wave_max(dmax_l);
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
       if (i < k.np) {
         const int ix = (J + (i >> 6)) * 64 + (i & 63);
         R1[i] = i < n ? -(HX[i] + G[i]) + P1[i] + aW1[ix] : 0.0;
         R2[i] = i < n ? P2[i] + aW2[ix] : 0.0;
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {   // border column e of M: H~ column + A'DA column (+ its variable-bound weight on the diagonal)
+          double v = i < n ? k.Hb[(size_t)e * k.np + i] + MB[e * k.np + i] : 0.0;
+          if (i == nc + e) { v += e < nb ? aD[ix] : 1.0; dmax_l = fmax(dmax_l, v); }
+          MB[e * k.np + i] = v;
+        }
       }
     }
+    const double dmax = wave_max(dmax_l);
     __syncthreads();
     if (P.dump && b == 0 && P.dump_stage == 1 && it == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
 #pragma unroll
@@ -817,15 +917,94 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
             const int r = 16 * I + k.q + 4 * p, cc = 16 * Jt + k.c;
             if (r < n && cc < n) { P.dump[r * n + cc] = acc[Tri<T>::idx(I, Jt)][p]; if (I != Jt || cc >= r) P.dump[cc * n + r] = acc[Tri<T>::idx(I, Jt)][p]; }
           }
+      for (int e = 0; e < nb; ++e)
+        for (int i = lane; i < n; i += 64) { P.dump[i * n + nc + e] = MB[e * k.np + i]; P.dump[(nc + e) * n + i] = MB[e * k.np + i]; }
       for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
     }
     STAMP(4);
     v4d rh[T];
-    rhs_load<T>(k, rh, R1, R2);
-    if (reg_factor<T>(k, acc, YL, rh, 1e-30 * dmax)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
+    double Ubb[NBB][NBB];
+    {
+      const double* vin[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
+      rhs_load<T, 2 + NB>(k, rh, vin);
+    }
+    int fbad = reg_factor<T>(k, acc, YL, rh, 1e-30 * dmax);
+    if (NB > 0) {   // bordered factor: u_e = U^-T m_e came out of the forward sweep; S = M_bb - u'u is factorised as scalars
+      double* vout[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
+      rhs_store<T, 2 + NB>(k, rh, vout);
+      __syncthreads();
+      double S[NBB][NBB];
+#pragma unroll
+      for (int e = 0; e < NB; ++e)
+#pragma unroll
+        for (int f = e; f < NB; ++f) {
+          double dsum = 0.0;
+          for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < nc) dsum = fma(MB[e * k.np + i], MB[f * k.np + i], dsum); }
+          S[e][f] = MB[e * k.np + nc + f] - wave_sum(dsum);
+        }
+#pragma unroll
+      for (int e = 0; e < NB; ++e) {
+        double dd = S[e][e];
+#pragma unroll
+        for (int g2 = 0; g2 < e; ++g2) dd -= Ubb[g2][e] * Ubb[g2][e];
+        if (!(dd > 1e-30 * dmax)) { if (!(fabs(dd) < INFINITY)) fbad = 1; dd = 1e-30 * dmax; }
+        Ubb[e][e] = sqrt(dd);
+#pragma unroll
+        for (int f = e + 1; f < NB; ++f) {
+          double tt = S[e][f];
+#pragma unroll
+          for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * Ubb[g2][f];
+          Ubb[e][f] = tt / Ubb[e][e];
+        }
+      }
+    }
+    if (fbad) { flag = (res_ok || have_saved) ? 2 : -1; break; }
+    // border part of a solve: R holds y_c = U^-T b_c (core) and b_b (border); leaves the border solution in R[nc+e]
+    // and y_c - sum_e u_e x_e in the core, ready for the backward sweep
+    auto border_solve = [&](double* R) {
+      if (NB > 0) {
+        double yb[NBB], xb[NBB];
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+          double dsum = 0.0;
+          for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < nc) dsum = fma(MB[e * k.np + i], R[i], dsum); }
+          double tt = R[nc + e] - wave_sum(dsum);
+#pragma unroll
+          for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * yb[g2];
+          yb[e] = tt / Ubb[e][e];
+        }
+#pragma unroll
+        for (int e = NB - 1; e >= 0; --e) {
+          double tt = yb[e];
+#pragma unroll
+          for (int f = e + 1; f < NB; ++f) tt -= Ubb[e][f] * xb[f];
+          xb[e] = tt / Ubb[e][e];
+        }
+        __syncthreads();
+        for (int h = 0; h < 2; ++h) {
+          const int i = lane + 64 * h;
+          if (i < nc) {
+            double r = R[i];
+#pragma unroll
+            for (int e = 0; e < NB; ++e) r = fma(-MB[e * k.np + i], xb[e], r);
+            R[i] = r;
+          }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int e = 0; e < NB; ++e) R[nc + e] = xb[e];
+        }
+        __syncthreads();
+      }
+    };
+    if (NB > 0) {
+      border_solve(R1); border_solve(R2);
+      const double* vin[2] = {R1, R2};
+      rhs_load<T, 2>(k, rh, vin);
+    }
     STAMP(5);
     reg_backward<T>(k, acc, YL, rh, SCR);
-    rhs_store<T>(k, rh, R1, R2);
+    { double* vout[2] = {R1, R2}; rhs_store<T, 2>(k, rh, vout); }
     __syncthreads();
     STAMP(6);
     if (P.dump && b == 0 && P.dump_stage == 2 && it == P.dump_iter) {
@@ -845,7 +1024,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     // ================= pass 2: va = G dxa, vc = G dxc =================
     {
       const double* vin[2] = {R1, R2}; double* rout[2] = {aVA, aVC};
-      pass_Av<T, 2, true>(k, vin, rout, P1);   // fused: P1 = A~' w_cor
+      pass_Av<T, NB, 2, true>(k, vin, rout, P1);   // fused: P1 = A~' w_cor
       for (int jb = 0; jb < k.JB; ++jb) {
         const int i = jb * 64 + lane;
         aVA[(J + jb) * 64 + lane] = i < n ? R1[i] : 0.0;
@@ -899,17 +1078,24 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
     }
     __syncthreads();
     {
-      rhs_load<T>(k, rh, DX, nullptr);
+      const double* vin[1] = {DX}; double* vout[1] = {DX};
+      rhs_load<T, 1>(k, rh, vin);
       reg_forward<T>(k, acc, YL, rh);
+      if (NB > 0) {
+        rhs_store<T, 1>(k, rh, vout);
+        __syncthreads();
+        border_solve(DX);
+        rhs_load<T, 1>(k, rh, vin);
+      }
       reg_backward<T>(k, acc, YL, rh, SCR);
-      rhs_store<T>(k, rh, DX, nullptr);
+      rhs_store<T, 1>(k, rh, vout);
     }
     __syncthreads();
     STAMP(10);
     // ================= pass 4: G dx_cor =================
     {
       const double* vin[1] = {DX}; double* rout[1] = {aW2};  // W2 reused for G dx_cor
-      pass_Av<T, 1, false>(k, vin, rout, nullptr);
+      pass_Av<T, NB, 1, false>(k, vin, rout, nullptr);
       for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aW2[(J + jb) * 64 + lane] = i < n ? DX[i] : 0.0; }
     }
     STAMP(11);
@@ -1038,7 +1224,7 @@ template <int T> __global__ __launch_bounds__(64) void qp_solve_kernel(QpParams 
   }
   if (have_x) {  // objective at the returned point, in the caller's units (H~,g~ scaling is objective preserving)
     __syncthreads();
-    hx_tiles<T>(k, X, HX);
+    hx_full();
     __syncthreads();
     double fl = 0;
     for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < n) fl += 0.5 * X[i] * HX[i] + G[i] * X[i]; }
@@ -1099,7 +1285,13 @@ __global__ void mfma_selftest_kernel(const double* Am, const double* Bm, double*
 // ---------------------------------------------------------------------------------------------
 void qp_make_dims(int n, int m, QpDims* d) {
   d->n = n; d->m = m;
-  d->T = (n + 15) / 16; d->np = 16 * d->T;
+  // 1..4 trailing variables (the slack columns of the LTV-MPC QPs: nV = 2N + 1 or 2N + 4) are a *border*: they are
+  // handled on the VALU instead of costing a whole 16-wide tile row/column of MFMA work and operand traffic
+  const int rem = n % 16;
+  if (n >= 16 && rem >= 1 && rem <= 4) { d->T = n / 16; d->nb = rem; } else { d->T = (n + 15) / 16; d->nb = 0; }
+  d->NB = d->nb == 0 ? 0 : (d->nb == 1 ? 1 : 4);
+  d->nc = 16 * d->T;
+  d->np = d->nc + (d->nb ? 16 : 0);
   d->Kq = (m + 3) / 4;
   d->J = (d->Kq + 15) / 16;
   d->JB = (d->np + 63) / 64;
@@ -1111,20 +1303,32 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->off_gw = off; off += d->np;
   d->off_E = off; off += d->np;
   d->off_F = off; off += (size_t)(d->J > 0 ? d->J : 1) * 64;
+  d->off_Ab = off; off += (size_t)4 * (d->J > 0 ? d->J : 1) * 64;
+  d->off_Hb = off; off += (size_t)4 * d->np;
   d->off_rows = off; off += (size_t)R_NARR * d->rowlen;
   d->off_save = off; off += d->np + d->rowlen;
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
-  d->lds_solve = ((size_t)V_NARR * d->np + 16 * 17 + 16 + (size_t)d->T * 272) * sizeof(double);
+  d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272) * sizeof(double);
   d->lds_prep = ((size_t)d->np + 16 * (size_t)(4 * d->Kq + 1)) * sizeof(double);
 }
 
-template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_solve_kernel<T>),
+template <int T, int NB> static hipError_t launch_solve_TN(const QpParams& P, int batch, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_solve_kernel<T, NB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_solve);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(qp_solve_kernel<T>, dim3(batch), dim3(64), P.d.lds_solve, st, P);
+  hipLaunchKernelGGL((qp_solve_kernel<T, NB>), dim3(batch), dim3(64), P.d.lds_solve, st, P);
   return hipGetLastError();
+}
+template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, hipStream_t st) {
+  switch (P.d.NB) {
+    case 0: return launch_solve_TN<T, 0>(P, batch, st);
+#ifndef QP_NO_BORDER
+    case 1: return launch_solve_TN<T, 1>(P, batch, st);
+    case 4: return launch_solve_TN<T, 4>(P, batch, st);
+#endif
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid) {
@@ -1146,7 +1350,7 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     case 5: return launch_solve_T<5>(P, batch, st);
     case 6: return launch_solve_T<6>(P, batch, st);
     case 7: return launch_solve_T<7>(P, batch, st);
-    case 8: return launch_solve_T<8>(P, batch, st);
+    case 8: return launch_solve_TN<8, 0>(P, batch, st);
 #endif
     default: return hipErrorInvalidValue;
   }

@@ -49,12 +49,13 @@ def test_00_mfma_layout_selftest(fm):
     assert fm.lib().fsaempc_selftest_mfma() == 0, fm.lib().fsaempc_last_error()
 
 
-def test_01_normal_matrix_dump_matches_numpy(fm, torch_, orc, otrack):
-    """First iteration internals of instance 0: M = H~ + diag + A~'DA~ (MFMA path), p1..p3, Hx against numpy."""
+@pytest.mark.parametrize("model,N", [(0, 12), (0, 8), (0, 40), (1, 8), (1, 7), (0, 9), (1, 40)])
+def test_01_normal_matrix_dump_matches_numpy(fm, torch_, orc, otrack, model, N):
+    """First iteration internals of instance 0: M = H~ + diag + A~'DA~ (MFMA core + VALU border columns), p1..p3, Hx
+    against numpy.  The cases cover no border (nV mod 16 outside 1..4), 1-, 2-, 3- and 4-column borders."""
     torch = torch_
-    N = 12
-    x0, xl, ul, xr = orc.synth_instances(0, N, 0.05, otrack.L, 20190, [1, 2])
-    q = orc.build_qp_batch(0, otrack, N, 0.05, x0, xr, xl, ul)
+    x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, [1, 2])
+    q = orc.build_qp_batch(model, otrack, N, 0.05, x0, xr, xl, ul)
     n, m = q["g"].shape[1], q["lbA"].shape[1]
     dump = torch.zeros(4 * n * n + 8 * (n + m), dtype=torch.float64, device="cuda")
     fm.lib().fsaempc_debug_set_dump(C.c_void_p(dump.data_ptr()), 1)
