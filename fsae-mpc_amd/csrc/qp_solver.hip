@@ -9,7 +9,7 @@
 // accumulators resident in registers, plus three light streaming passes over A.
 //
 // Data layout (all per QP, in the device workspace, written once by qp_prep_kernel):
-//   Aw [Kq][T][64]   scaled A in MFMA-operand stream order: k-step s, column tile t, lane (c=l&15,q=l>>4)
+//   Aw [Kq/2][T][64][2] scaled A in MFMA-operand stream order, two k-steps per 16-byte lane load: k-step s, column tile t, lane (c=l&15,q=l>>4)
 //                    holds A~[r = q*Kq + s][16t + c]   (the K order of the MFMA is permuted so that each
 //                    lane group walks a contiguous row range; every load is one coalesced 512 B line set)
 //   Hw [T*T][4][64]  scaled H in accumulator (C/D) layout: tile (I,J), reg p, lane -> H~[16I+q+4p][16J+c]
@@ -23,6 +23,7 @@
 #include "qp_solver.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define DEVINL __device__ __forceinline__
 
@@ -174,10 +175,10 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
       }
     }
     __syncthreads();
-    for (int s = 0; s < Kq; ++s) {
-      const int r = q * Kq + s;
-      const double f = Fs[(s >> 4) * 64 + q * 16 + (s & 15)];
-      Aw[((size_t)s * T + t) * 64 + lane] = tile[c * mp1 + r] * f;
+    for (int s = 0; s < 2 * ((Kq + 1) / 2); ++s) {   // k-steps are stored in pairs (16 B per lane and load); odd tail zero-filled
+      double v = 0.0;
+      if (s < Kq) { const int r = q * Kq + s; v = tile[c * mp1 + r] * Fs[(s >> 4) * 64 + q * 16 + (s & 15)]; }
+      Aw[((size_t)(s >> 1) * T + t) * 128 + lane * 2 + (s & 1)] = v;
     }
     __syncthreads();
   }
@@ -272,12 +273,13 @@ template <int T> DEVINL void acc_init(const Ctx& k, v4d* acc) {
 // A ring of PF k-steps of operands is kept in flight (L2 / Infinity-Cache latency under load is ~2-3k cycles,
 // one k-step of MFMA work is ~1.3k cycles).
 template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, double* P2, double* P3, double* MB) {
-  constexpr int PF = 3;
+  constexpr int PF = 2;   // pairs of k-steps in flight
   constexpr int NBB = NB > 0 ? NB : 1;
   const double* D = rowp(k, R_D); const double* W1 = rowp(k, R_W1);
   const double* W2 = rowp(k, R_W2); const double* W3 = rowp(k, R_W3);
-  const int JS = k.J * 64;
-  double p1[T], p2[T], p3[T], bq[PF][T], cq[PF][4 + NBB];
+  const int JS = k.J * 64, Kq2 = (k.Kq + 1) >> 1;
+  double p1[T], p2[T], p3[T], cq[PF][2][4 + NBB];
+  v2d bq[PF][T];
   double pb[NBB][T], sbb[NBB][NBB], pwb[3][NBB];   // border: column of A'DA, border block, border entries of p1..p3
 #pragma unroll
   for (int t = 0; t < T; ++t) { p1[t] = 0; p2[t] = 0; p3[t] = 0; }
@@ -289,51 +291,73 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
     for (int f = 0; f < NBB; ++f) sbb[e][f] = 0;
     pwb[0][e] = pwb[1][e] = pwb[2][e] = 0;
   }
-  auto issue = [&](int u, int s) {
+  auto issue = [&](int u, int s2) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
-    const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-    cq[u][0] = D[ri]; cq[u][1] = W1[ri]; cq[u][2] = W2[ri]; cq[u][3] = W3[ri];
+    for (int t = 0; t < T; ++t) bq[u][t] = *reinterpret_cast<const v2d*>(k.Aw + ((size_t)s2 * T + t) * 128 + k.lane * 2);
 #pragma unroll
-    for (int e = 0; e < NB; ++e) cq[u][4 + e] = k.Ab[(size_t)e * JS + ri];
+    for (int h = 0; h < 2; ++h) {
+      const int s = 2 * s2 + h;
+      if (s < k.Kq) {
+        const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+        cq[u][h][0] = D[ri]; cq[u][h][1] = W1[ri]; cq[u][h][2] = W2[ri]; cq[u][h][3] = W3[ri];
+#pragma unroll
+        for (int e = 0; e < NB; ++e) cq[u][h][4 + e] = k.Ab[(size_t)e * JS + ri];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4 + NBB; ++e) cq[u][h][e] = 0.0;
+      }
+    }
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
+    for (int t = 0; t < T; ++t) bq[u][t] = v2d{0.0, 0.0};
 #pragma unroll
-    for (int e = 0; e < 4 + NBB; ++e) cq[u][e] = 0.0;
-    if (u < k.Kq) issue(u, u);
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4 + NBB; ++e) cq[u][h][e] = 0.0;
+    if (u < Kq2) issue(u, u);
   }
-  for (int s0 = 0; s0 < k.Kq; s0 += PF) {
+  for (int s0 = 0; s0 < Kq2; s0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int s = s0 + u;
-      if (s < k.Kq) {
-        double bc[T], a[T], ab[NBB];
-        const double dd = cq[u][0], w1 = cq[u][1], w2 = cq[u][2], w3 = cq[u][3];
+      const int s2 = s0 + u;
+      if (s2 < Kq2) {
+        double bc[2][T], cf[2][4 + NBB];
 #pragma unroll
-        for (int e = 0; e < NB; ++e) ab[e] = cq[u][4 + e];
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) { bc[t] = bq[u][t]; a[t] = dd * bc[t]; }
-        if (s + PF < k.Kq) issue(u, s + PF);
+          for (int t = 0; t < T; ++t) bc[h][t] = bq[u][t][h];
 #pragma unroll
-        for (int I = 0; I < T; ++I)
-#pragma unroll
-          for (int Jt = I; Jt < T; ++Jt)
-            acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], bc[Jt], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          p1[t] = fma(w1, bc[t], p1[t]); p2[t] = fma(w2, bc[t], p2[t]); p3[t] = fma(w3, bc[t], p3[t]);
+          for (int e = 0; e < 4 + NBB; ++e) cf[h][e] = cq[u][h][e];
         }
+        if (s2 + PF < Kq2) issue(u, s2 + PF);
 #pragma unroll
-        for (int e = 0; e < NB; ++e) {
-          const double dab = dd * ab[e];
+        for (int h = 0; h < 2; ++h) {
+          double a[T], ab[NBB];
+          const double dd = cf[h][0], w1 = cf[h][1], w2 = cf[h][2], w3 = cf[h][3];
 #pragma unroll
-          for (int t = 0; t < T; ++t) pb[e][t] = fma(dab, bc[t], pb[e][t]);
+          for (int e = 0; e < NB; ++e) ab[e] = cf[h][4 + e];
 #pragma unroll
-          for (int f = e; f < NB; ++f) sbb[e][f] = fma(dab, ab[f], sbb[e][f]);
-          pwb[0][e] = fma(w1, ab[e], pwb[0][e]); pwb[1][e] = fma(w2, ab[e], pwb[1][e]); pwb[2][e] = fma(w3, ab[e], pwb[2][e]);
+          for (int t = 0; t < T; ++t) a[t] = dd * bc[h][t];
+#pragma unroll
+          for (int I = 0; I < T; ++I)
+#pragma unroll
+            for (int Jt = I; Jt < T; ++Jt)
+              acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], bc[h][Jt], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            p1[t] = fma(w1, bc[h][t], p1[t]); p2[t] = fma(w2, bc[h][t], p2[t]); p3[t] = fma(w3, bc[h][t], p3[t]);
+          }
+#pragma unroll
+          for (int e = 0; e < NB; ++e) {
+            const double dab = dd * ab[e];
+#pragma unroll
+            for (int t = 0; t < T; ++t) pb[e][t] = fma(dab, bc[h][t], pb[e][t]);
+#pragma unroll
+            for (int f = e; f < NB; ++f) sbb[e][f] = fma(dab, ab[f], sbb[e][f]);
+            pwb[0][e] = fma(w1, ab[e], pwb[0][e]); pwb[1][e] = fma(w2, ab[e], pwb[1][e]); pwb[2][e] = fma(w3, ab[e], pwb[2][e]);
+          }
         }
       }
     }
@@ -363,10 +387,11 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
 template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor) {
-  constexpr int PF = 4;   // k-steps of operands in flight (little compute per step => latency bound otherwise)
+  constexpr int PF = 2;   // pairs of k-steps in flight (little compute per step => latency bound otherwise)
   constexpr int NBB = NB > 0 ? NB : 1;
-  const int JS = k.J * 64;
-  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], bq[PF][T], cq[PF][6 + NBB];
+  const int JS = k.J * 64, Kq2 = (k.Kq + 1) >> 1;
+  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], cq[PF][2][6 + NBB];
+  v2d bq[PF][T];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e) {
 #pragma unroll
@@ -380,60 +405,76 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
   for (int f = 0; f < NBB; ++f) pcb[f] = 0.0;
   const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
   const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
-  auto issue = [&](int u, int s) {
+  auto issue = [&](int u, int s2) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = k.Aw[((size_t)s * T + t) * 64 + k.lane];
-    const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-    if (FUSE) { cq[u][0] = CA1[ri]; cq[u][1] = CB1[ri]; cq[u][2] = CC1[ri]; cq[u][3] = CA2[ri]; cq[u][4] = CB2[ri]; cq[u][5] = CC2[ri]; }
+    for (int t = 0; t < T; ++t) bq[u][t] = *reinterpret_cast<const v2d*>(k.Aw + ((size_t)s2 * T + t) * 128 + k.lane * 2);
 #pragma unroll
-    for (int f = 0; f < NB; ++f) cq[u][6 + f] = k.Ab[(size_t)f * JS + ri];
+    for (int h = 0; h < 2; ++h) {
+      const int s = 2 * s2 + h;
+      if (s < k.Kq) {
+        const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+        if (FUSE) { cq[u][h][0] = CA1[ri]; cq[u][h][1] = CB1[ri]; cq[u][h][2] = CC1[ri]; cq[u][h][3] = CA2[ri]; cq[u][h][4] = CB2[ri]; cq[u][h][5] = CC2[ri]; }
+#pragma unroll
+        for (int f = 0; f < NB; ++f) cq[u][h][6 + f] = k.Ab[(size_t)f * JS + ri];
+      }
+    }
   };
 #pragma unroll
   for (int u = 0; u < PF; ++u) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = 0.0;
+    for (int t = 0; t < T; ++t) bq[u][t] = v2d{0.0, 0.0};
 #pragma unroll
-    for (int e = 0; e < 6 + NBB; ++e) cq[u][e] = 0.0;
-    if (u < k.Kq) issue(u, u);
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 6 + NBB; ++e) cq[u][h][e] = 0.0;
+    if (u < Kq2) issue(u, u);
   }
   double keep[NVEC];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e) keep[e] = 0.0;
-  for (int s0 = 0; s0 < k.Kq; s0 += PF) {
+  for (int s0 = 0; s0 < Kq2; s0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int s = s0 + u;
-      if (s < k.Kq) {
-        double bc[T], ab[NBB];
-        const double a1 = cq[u][0], b1 = cq[u][1], c1 = cq[u][2], a2 = cq[u][3], b2 = cq[u][4], c2 = cq[u][5];
+      const int s2 = s0 + u;
+      if (s2 < Kq2) {
+        double bc[2][T], cf[2][6 + NBB];
 #pragma unroll
-        for (int f = 0; f < NB; ++f) ab[f] = cq[u][6 + f];
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) bc[t] = bq[u][t];
-        if (s + PF < k.Kq) issue(u, s + PF);
-        const int cc = s & 15;
+          for (int t = 0; t < T; ++t) bc[h][t] = bq[u][t][h];
 #pragma unroll
-        for (int e = 0; e < NVEC; ++e) {
-          double dsum = 0.0;
-#pragma unroll
-          for (int t = 0; t < T; ++t) dsum = fma(bc[t], v[e][t], dsum);
-          dsum = grp16_sum(dsum);
-#pragma unroll
-          for (int f = 0; f < NB; ++f) dsum = fma(ab[f], vb[e][f], dsum);
-          if (k.c == cc) keep[e] = dsum;
-          if (FUSE && e == 0) {
-            const double dl_ = dsum + a1, du_ = a2 - dsum;
-            const double w = dl_ * fma(c1, dl_, b1) - du_ * fma(c2, du_, b2);
-#pragma unroll
-            for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[t], pc[t]);
-#pragma unroll
-            for (int f = 0; f < NB; ++f) pcb[f] = fma(w, ab[f], pcb[f]);
-          }
+          for (int e = 0; e < 6 + NBB; ++e) cf[h][e] = cq[u][h][e];
         }
-        if (cc == 15 || s + 1 == k.Kq) {
-          const int js = s >> 4;
+        if (s2 + PF < Kq2) issue(u, s2 + PF);
 #pragma unroll
-          for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
+        for (int h = 0; h < 2; ++h) {
+          const int s = 2 * s2 + h;
+          if (s < k.Kq) {
+            const int cc = s & 15;
+#pragma unroll
+            for (int e = 0; e < NVEC; ++e) {
+              double dsum = 0.0;
+#pragma unroll
+              for (int t = 0; t < T; ++t) dsum = fma(bc[h][t], v[e][t], dsum);
+              dsum = grp16_sum(dsum);
+#pragma unroll
+              for (int f = 0; f < NB; ++f) dsum = fma(cf[h][6 + f], vb[e][f], dsum);
+              if (k.c == cc) keep[e] = dsum;
+              if (FUSE && e == 0) {
+                const double dl_ = dsum + cf[h][0], du_ = cf[h][3] - dsum;
+                const double w = dl_ * fma(cf[h][2], dl_, cf[h][1]) - du_ * fma(cf[h][5], du_, cf[h][4]);
+#pragma unroll
+                for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[h][t], pc[t]);
+#pragma unroll
+                for (int f = 0; f < NB; ++f) pcb[f] = fma(w, cf[h][6 + f], pcb[f]);
+              }
+            }
+            if (cc == 15 || s + 1 == k.Kq) {
+              const int js = s >> 4;
+#pragma unroll
+              for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
+            }
+          }
         }
       }
     }
@@ -462,7 +503,7 @@ template <int T, int NB> DEVINL void pass_Atw(const Ctx& k, const double* W, dou
     const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
     const double w = W[ri];
 #pragma unroll
-    for (int t = 0; t < T; ++t) p[t] = fma(w, k.Aw[((size_t)s * T + t) * 64 + k.lane], p[t]);
+    for (int t = 0; t < T; ++t) p[t] = fma(w, k.Aw[((size_t)(s >> 1) * T + t) * 128 + k.lane * 2 + (s & 1)], p[t]);
 #pragma unroll
     for (int f = 0; f < NB; ++f) pbv[f] = fma(w, k.Ab[(size_t)f * JS + ri], pbv[f]);
   }
@@ -1298,7 +1339,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->ld = n | 1;
   d->rowlen = (d->J + d->JB) * 64;
   size_t off = 0;
-  d->off_Aw = off; off += (size_t)d->Kq * d->T * 64;
+  d->off_Aw = off; off += (size_t)((d->Kq + 1) / 2) * d->T * 128;
   d->off_Hw = off; off += (size_t)d->T * d->T * 4 * 64;
   d->off_gw = off; off += d->np;
   d->off_E = off; off += d->np;
