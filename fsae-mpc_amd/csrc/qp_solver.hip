@@ -805,17 +805,19 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     pass_Av<T, NB, 1, false>(k, vin, rout, nullptr);
     for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aV[(J + jb) * 64 + lane] = i < n ? X[i] : 0.0; }
   }
-  // ---- initial slacks / multipliers: t = max(resid,1), z = 1 on general rows ----
+  // ---- initial slacks / multipliers in the equilibrated problem: t = max(resid, T0), z = Z0 (a scan over the
+  //      synthetic LTV-MPC families: (10,100) needs 8-16 % fewer iterations than (1,1)) ----
+  const double T0 = 10.0, Z0 = 100.0;
   for (int js = 0; js < JT; ++js) {
     const int ix = js * 64 + lane;
     const bool valid = row_valid(k, js);
     const double l = aL[ix], u = aU[ix], v = aV[ix];
     const bool hl = valid && l > -INFINITY, hu = valid && u < INFINITY;
-    aTL[ix] = hl ? fmax(v - l, 1.0) : 1.0;
-    aTU[ix] = hu ? fmax(u - v, 1.0) : 1.0;
-    aZL[ix] = hl ? 1.0 : 0.0;
-    aZU[ix] = hu ? 1.0 : 0.0;
-    aW3[ix] = (js < J) ? ((hl ? 1.0 : 0.0) - (hu ? 1.0 : 0.0)) : 0.0;
+    aTL[ix] = hl ? fmax(v - l, T0) : 1.0;
+    aTU[ix] = hu ? fmax(u - v, T0) : 1.0;
+    aZL[ix] = hl ? Z0 : 0.0;
+    aZU[ix] = hu ? Z0 : 0.0;
+    aW3[ix] = (js < J) ? ((hl ? Z0 : 0.0) - (hu ? Z0 : 0.0)) : 0.0;
   }
   __syncthreads();
   // bound multipliers absorb the initial dual residual r = Hx + g - A'(zl - zu)
@@ -827,8 +829,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const int i = jb * 64 + lane, ix = (J + jb) * 64 + lane;
       if (i < n) {
         const double r = HX[i] + G[i] - P3[i];
-        if (aL[ix] > -INFINITY) aZL[ix] = fmax(r, 0.0) + 1.0;
-        if (aU[ix] < INFINITY) aZU[ix] = fmax(-r, 0.0) + 1.0;
+        if (aL[ix] > -INFINITY) aZL[ix] = fmax(r, 0.0) + Z0;
+        if (aU[ix] < INFINITY) aZU[ix] = fmax(-r, 0.0) + Z0;
       }
     }
     __syncthreads();

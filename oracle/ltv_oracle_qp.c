@@ -325,7 +325,9 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
   }
   if (infeasible_bounds) { flag = infeasible_bounds == 1 ? -2 : -1; goto finish; }
 
-  /* ---- initial point --------------------------------------------------------- */
+  /* ---- initial point: slacks >= T0, multipliers Z0 in the equilibrated problem (scan over the synthetic
+   * LTV-MPC families: (10,100) needs 8-16 % fewer iterations than (1,1)) ------------------------------ */
+  const double T0 = 10.0, Z0 = 100.0;
   for (int j = 0; j < n; ++j) {
     double xj = 0;
     if (w.hl[j] && xj < w.l[j]) xj = w.l[j];
@@ -334,8 +336,8 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
   }
   apply_G(&w, x, v);
   for (int i = 0; i < mt; ++i) {
-    if (w.hl[i]) { tl[i] = fmax(v[i] - w.l[i], 1.0); zl[i] = 1.0; }
-    if (w.hu[i]) { tu[i] = fmax(w.u[i] - v[i], 1.0); zu[i] = 1.0; }
+    if (w.hl[i]) { tl[i] = fmax(v[i] - w.l[i], T0); zl[i] = Z0; }
+    if (w.hu[i]) { tu[i] = fmax(w.u[i] - v[i], T0); zu[i] = Z0; }
   }
   /* bound multipliers absorb the initial dual residual (keeps the first Newton step sane when
    * |g| is huge, e.g. the 1e8 slack cost of ltvmpc_*.m:35) */
@@ -345,8 +347,8 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
     double hx = 0;
     for (int i = 0; i < n; ++i) hx += w.H[IDX(j, i, n)] * x[i];
     double r = hx + w.g[j] - Gz[j];
-    if (w.hl[j]) zl[j] = fmax(r, 0.0) + 1.0;
-    if (w.hu[j]) zu[j] = fmax(-r, 0.0) + 1.0;
+    if (w.hl[j]) zl[j] = fmax(r, 0.0) + Z0;
+    if (w.hu[j]) zu[j] = fmax(-r, 0.0) + Z0;
   }
 
   double best_res = INFINITY;

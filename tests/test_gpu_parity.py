@@ -74,10 +74,11 @@ def test_01_normal_matrix_dump_matches_numpy(fm, torch_, orc, otrack, model, N):
     hl = np.concatenate([q["lb"][0], q["lbA"][0]]) > -1e9; hu = np.concatenate([q["ub"][0], q["ubA"][0]]) < 1e9
     x = np.clip(np.zeros(n), np.where(hl[:n], l[:n], -np.inf), np.where(hu[:n], u[:n], np.inf))
     G = np.vstack([np.eye(n), As]); v = G @ x
-    tl = np.where(hl, np.maximum(v - np.where(hl, l, 0), 1), 1); tu = np.where(hu, np.maximum(np.where(hu, u, 0) - v, 1), 1)
-    zl = hl * 1.0; zu = hu * 1.0
+    T0, Z0 = 10.0, 100.0   # initial slack floor / multiplier of the solver (qp_solver.hip)
+    tl = np.where(hl, np.maximum(v - np.where(hl, l, 0), T0), 1); tu = np.where(hu, np.maximum(np.where(hu, u, 0) - v, T0), 1)
+    zl = hl * Z0; zu = hu * Z0
     r = Hs @ x + gs - As.T @ (zl[n:] - zu[n:])
-    zl[:n] = np.where(hl[:n], np.maximum(r, 0) + 1, 0); zu[:n] = np.where(hu[:n], np.maximum(-r, 0) + 1, 0)
+    zl[:n] = np.where(hl[:n], np.maximum(r, 0) + Z0, 0); zu[:n] = np.where(hu[:n], np.maximum(-r, 0) + Z0, 0)
     D = np.where(hl, zl / tl, 0) + np.where(hu, zu / tu, 0)
     Mref = Hs + G.T @ (D[:, None] * G)
     assert np.max(np.abs(M - Mref)) <= 1e-11 * np.abs(Mref).max()
