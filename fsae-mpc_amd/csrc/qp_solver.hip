@@ -83,8 +83,9 @@ template <int T> struct Tri {
 // ---------------------------------------------------------------------------------------------
 // qp_prep_kernel: scaling (E columns, F rows), repack of A and H, scaled g / bounds.  One wave per QP.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
-  const int b = blockIdx.x, lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+__global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
+  // one 256-thread workgroup per QP (4 wavefronts share the LDS staging tile; HBM-bound: ~0.5 MB moved per QP)
+  const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
   const QpDims& d = P.d;
   const int n = d.n, m = d.m, T = d.T, Kq = d.Kq, J = d.J, JB = d.JB, np = d.np, nc = d.nc, nb = d.nb;
   const double* H = P.H + (P.shared_HA ? 0 : (size_t)b * n * n);
@@ -102,33 +103,35 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
   double* Ur = ws + d.off_rows + 1 * (size_t)d.rowlen;
   extern __shared__ double lds[];
   double* Esh = lds;            // np
-  double* tile = lds + np;      // 16 x (mp+1) staging for the A transpose
+  double* red = lds + np;       // 4 partial maxima
+  double* tile = red + 4;       // 16 x (4Kq+1) staging for the A transpose
 
   // ---- column scaling E_j = 1/sqrt(H_jj), or 1/max|A_:j| where H_jj ~ 0 (slack columns) ----
-  for (int j = lane; j < np; j += 64) {
+  for (int j = tid; j < np; j += 256) {
     double e = 1.0;
     if (j < n) {
       double hjj = H[(size_t)j * n + j];
       if (hjj > 1e-12) e = 1.0 / sqrt(hjj);
-      else e = -1.0;  // resolved below with a wave-cooperative column max
+      else e = -1.0;  // resolved below with a cooperative column max
     } else e = 0.0;   // padded columns carry zeros
     Esh[j] = e;
   }
   __syncthreads();
   for (int j = 0; j < n; ++j) {
-    if (Esh[j] < 0) {  // wave-uniform
+    if (Esh[j] < 0) {  // uniform over the workgroup
       double cm = 0;
-      for (int r = lane; r < m; r += 64) cm = fmax(cm, fabs(A[(size_t)j * m + r]));
+      for (int r = tid; r < m; r += 256) cm = fmax(cm, fabs(A[(size_t)j * m + r]));
       cm = wave_max(cm);
+      if (lane == 0) red[w] = cm;
       __syncthreads();
-      if (lane == 0) Esh[j] = cm > 1e-12 ? 1.0 / cm : 1.0;
+      if (tid == 0) { const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); Esh[j] = mx > 1e-12 ? 1.0 / mx : 1.0; }
       __syncthreads();
     }
   }
-  for (int j = lane; j < np; j += 64) { Es[j] = Esh[j]; gw[j] = j < n ? g[j] * Esh[j] : 0.0; }
+  for (int j = tid; j < np; j += 256) { Es[j] = Esh[j]; gw[j] = j < n ? g[j] * Esh[j] : 0.0; }
 
-  // ---- row scaling F_r = 1/max_j |A[r][j] E_j| ; rows handled in owner layout ----
-  for (int js = 0; js < J; ++js) {
+  // ---- row scaling F_r = 1/max_j |A[r][j] E_j| ; rows handled in owner layout, one slot per wavefront and trip ----
+  for (int js = w; js < J; js += 4) {
     const int s = 16 * js + c, r = q * Kq + s;
     const bool valid = s < Kq && r < m;
     double rm = 0;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
     Lr[js * 64 + lane] = l;
     Ur[js * 64 + lane] = u;
   }
-  for (int jb = 0; jb < JB; ++jb) {
+  for (int jb = w; jb < JB; jb += 4) {
     const int i = jb * 64 + lane;
     double l = -INFINITY, u = INFINITY;
     if (i < n) {
@@ -158,24 +161,20 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
     Lr[(J + jb) * 64 + lane] = l;
     Ur[(J + jb) * 64 + lane] = u;
   }
-  __syncthreads();  // Fs visible (global, same wave) -- also orders the LDS tile reuse below
+  __syncthreads();  // Fs visible to the whole workgroup (global memory, same CU)
 
   // ---- A -> operand stream.  Column tile by column tile: coalesced column reads -> LDS -> lane order ----
-  const int mp1 = 4 * Kq + 1;  // padded LDS row length (odd => conflict-free across the 16 columns)
+  const int R4 = 4 * Kq, mp1 = R4 + 1;  // padded LDS row length (odd => conflict-free across the 16 columns)
   for (int t = 0; t < T; ++t) {
-    for (int cc = 0; cc < 16; ++cc) {
+    for (int e = tid; e < 16 * R4; e += 256) {
+      const int cc = e / R4, r = e - cc * R4;   // r = position in the permuted K order = row index (lane groups own contiguous rows)
       const int col = 16 * t + cc;
-      for (int r = lane; r < 4 * Kq; r += 64) {
-        double v = 0.0;
-        // LDS index space is (q*Kq + s) = position in the permuted K order; r here is that position
-        const int qq = r / Kq, ss = r - qq * Kq;
-        const int row = qq * Kq + ss;  // == r (rows are laid out contiguously per lane group)
-        if (col < nc && col < n && row < m) v = A[(size_t)col * m + row] * Esh[col];
-        tile[cc * mp1 + r] = v;
-      }
+      double v = 0.0;
+      if (col < nc && col < n && r < m) v = A[(size_t)col * m + r] * Esh[col];
+      tile[cc * mp1 + r] = v;
     }
     __syncthreads();
-    for (int s = 0; s < 2 * ((Kq + 1) / 2); ++s) {   // k-steps are stored in pairs (16 B per lane and load); odd tail zero-filled
+    for (int s = w; s < 2 * ((Kq + 1) / 2); s += 4) {   // k-steps are stored in pairs (16 B per lane and load); odd tail zero-filled
       double v = 0.0;
       if (s < Kq) { const int r = q * Kq + s; v = tile[c * mp1 + r] * Fs[(s >> 4) * 64 + q * 16 + (s & 15)]; }
       Aw[((size_t)(s >> 1) * T + t) * 128 + lane * 2 + (s & 1)] = v;
@@ -183,18 +182,18 @@ __global__ __launch_bounds__(64) void qp_prep_kernel(QpParams P) {
     __syncthreads();
   }
 
-  // ---- H -> accumulator-layout tiles (full T x T grid; symmetric read for coalescing) ----
-  for (int I = 0; I < T; ++I)
-    for (int Jt = 0; Jt < T; ++Jt)
-      for (int p = 0; p < 4; ++p) {
-        const int row = 16 * I + q + 4 * p, col = 16 * Jt + c;
-        double v = 0.0;
-        if (row < nc && col < nc && row < n && col < n) v = H[(size_t)row * n + col] * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
-        Hw[((size_t)(I * T + Jt) * 4 + p) * 64 + lane] = v;
-      }
-  for (int bb = 0; bb < 4; ++bb)
-    for (int i = lane; i < np; i += 64)
-      Hb[(size_t)bb * np + i] = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
+  // ---- H -> accumulator-layout tiles (T x T grid of the core; symmetric read for coalescing) ----
+  for (int idx = w; idx < T * T * 4; idx += 4) {
+    const int p = idx & 3, IJ = idx >> 2, I = IJ / T, Jt = IJ - I * T;
+    const int row = 16 * I + q + 4 * p, col = 16 * Jt + c;
+    double v = 0.0;
+    if (row < nc && col < nc && row < n && col < n) v = H[(size_t)row * n + col] * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
+    Hw[(size_t)idx * 64 + lane] = v;
+  }
+  for (int e = tid; e < 4 * np; e += 256) {
+    const int bb = e / np, i = e - bb * np;
+    Hb[e] = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1353,7 +1352,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
   d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272) * sizeof(double);
-  d->lds_prep = ((size_t)d->np + 16 * (size_t)(4 * d->Kq + 1)) * sizeof(double);
+  d->lds_prep = ((size_t)d->np + 4 + 16 * (size_t)(4 * d->Kq + 1)) * sizeof(double);
 }
 
 template <int T, int NB> static hipError_t launch_solve_TN(const QpParams& P, int batch, hipStream_t st) {
@@ -1378,7 +1377,7 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_prep);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(64), P.d.lds_prep, st, P);
+  hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(256), P.d.lds_prep, st, P);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_mid) { e = hipEventRecord(ev_mid, st); if (e != hipSuccess) return e; }
