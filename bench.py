@@ -40,11 +40,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N>1 path on a one-GPU box: every rank on cuda:0, gloo instead of RCCL (RCCL refuses two ranks on
+    # one device); never used for reported numbers
+    rehearsal = os.environ.get("FSAEMPC_BENCH_REHEARSAL") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
 
     model = fm.KINEMATIC if args.model == "kinematic" else fm.DYNAMIC
@@ -67,7 +70,8 @@ def main():
         out = fm.qp_solve_batch_device(*qp_args, workspace=ws)
         ws = out["workspace"]
         if world > 1:
-            out["x_all"] = shard.gather_rows(out["x"], Btot, rank, world)   # the only exchange: final gather over RCCL/xGMI
+            xs = out["x"].cpu() if rehearsal else out["x"]
+            out["x_all"] = shard.gather_rows(xs, Btot, rank, world)   # the only exchange: final gather over RCCL/xGMI
         return out
 
     def barrier():
@@ -90,14 +94,16 @@ def main():
     barrier()
     t_local = time.perf_counter() - t0
     L.fsaempc_qp_set_timing(0)
-    t_job = shard.max_over_ranks(t_local, device=dev)         # MAX over ranks
+    rdev = "cpu" if rehearsal else dev
+    t_job = shard.max_over_ranks(t_local, device=rdev)        # MAX over ranks
 
     flags = out["exitflag"].cpu().numpy()
     iters = out["iter"].cpu().numpy()
     solved = int((flags == 0).sum())
-    n_ok = shard.max_over_ranks(float(-solved), device=dev)   # min over ranks via max of negatives
+    n_ok = shard.max_over_ranks(float(-solved), device=rdev)  # min over ranks via max of negatives
+    solved_total = shard.sum_over_ranks(float(solved), device=rdev)
     mean_it = float(iters.mean())
-    value = Btot * args.steps / t_job
+    value = solved_total * args.steps / t_job                  # an instance counts only if its exit flag is 0
     flops_iter = 2.0 * nC * nV * nV + nV ** 3 / 3.0 + 4.0 * nC * nV + 2.0 * nV * nV
     flops_launch = flops_iter * mean_it * Bl
     k_ms = float(np.mean(solve_ms))
@@ -112,7 +118,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: batch=%d independent condensed QPs per GPU, %s model, N=%d, nV=%d, nC=%d, generic mode (dense H,g,A,bounds resident in HBM)"
                                % (Bl, args.model, N, nV, nC),
                    "batch_per_gpu": Bl, "global_batch": Btot, "track": "fsg2019", "seed": 20190,
-                   "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "tol_kkt": 1e-8,
+                   "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "solved_total": int(solved_total), "tol_kkt": 1e-8,
                    "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,
                    "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
         "roofline": {"bound": "mfma", "kernel": "qp_solve_kernel<%d>" % ((nV + 15) // 16), "achieved": achieved,

@@ -918,6 +918,34 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       for (int i = lane; i < k.np; i += 64) XS[i] = X[i];
       for (int js = 0; js < JT; ++js) LAMS[js * 64 + lane] = aW3[js * 64 + lane];
       have_saved = 1; saved_merit = merit;
+    } else if (merit > P.tol_loose && rp_rel <= P.tol_loose && gap_rel <= P.tol_loose) {
+      // Only the dual residual is in the way (the Newton steps lose accuracy once z/t passes ~1e19 and r_d creeps up):
+      // repair the certificate of a *copy* of the iterate by moving r_d into the bound multipliers, where a finite bound
+      // of the right sign exists; the copy qualifies as fall-back if its complementarity stays within tol_loose.
+      double dgap = 0, m_rd2 = 0, lamfix[2] = {0.0, 0.0};
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < n) {
+          const int ix = (J + (i >> 6)) * 64 + (i & 63);
+          const double lam = aW3[ix], gz = P3[i] + lam, r = HX[i] + G[i] - gz;
+          const double lam2 = lam + r, l = aL[ix], u = aU[ix], v = aV[ix];
+          const bool ok = lam2 >= 0 ? l > -INFINITY : u < INFINITY;
+          if (ok) { lamfix[h] = lam2; dgap += fabs(r) * fmax(0.0, lam2 >= 0 ? v - l : u - v); }
+          else {
+            lamfix[h] = lam;
+            const double sc = fmax(1.0, fmax(fabs(G[i]), fmax(fabs(HX[i]), fabs(gz))));
+            m_rd2 = fmax(m_rd2, fabs(r) / sc);
+          }
+        }
+      }
+      const double merit2 = fmax(wave_max(m_rd2), fmax(rp_rel, (gap + wave_sum(dgap)) / fmax(1.0, fabs(fval))));
+      if (merit2 <= P.tol_loose && merit2 < saved_merit) {
+        for (int i = lane; i < k.np; i += 64) XS[i] = X[i];
+        for (int js = 0; js < J; ++js) LAMS[js * 64 + lane] = aW3[js * 64 + lane];
+        for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < k.np) LAMS[(J + (i >> 6)) * 64 + (i & 63)] = i < n ? lamfix[h] : 0.0; }
+        have_saved = 1; saved_merit = merit2;
+      }
+      if (have_saved) { flag = 2; break; }
     } else if (have_saved && merit > P.tol_loose) { flag = 2; break; }
     if (merit < 0.9 * best_res) { best_res = merit; stall = 0; } else ++stall;
 

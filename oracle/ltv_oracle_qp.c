@@ -392,6 +392,28 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
       for (int j = 0; j < n; ++j) xs[j] = x[j];
       for (int i = 0; i < mt; ++i) lams[i] = (w.hl[i] ? zl[i] : 0) - (w.hu[i] ? zu[i] : 0);
       have_saved = 1; saved_merit = merit;
+    } else if (merit > opts.tol_loose && rp_rel <= opts.tol_loose && gap_rel <= opts.tol_loose) {
+      /* only the dual residual is in the way: repair the certificate of a copy of the iterate by moving r_d into the
+       * bound multipliers where a finite bound of the right sign exists (same rule as the HIP kernel) */
+      double dgap = 0, rd2 = 0;
+      for (int j = 0; j < n; ++j) {
+        double lam = (w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0);
+        double r = Hx[j] + w.g[j] - Gz[j], lam2 = lam + r;
+        int ok = lam2 >= 0 ? w.hl[j] : w.hu[j];
+        if (ok) { tmp[j] = lam2; dgap += fabs(r) * fmax(0.0, lam2 >= 0 ? v[j] - w.l[j] : w.u[j] - v[j]); }
+        else {
+          tmp[j] = lam;
+          double sc = fmax(1.0, fmax(fabs(w.g[j]), fmax(fabs(Hx[j]), fabs(Gz[j]))));
+          rd2 = fmax(rd2, fabs(r) / sc);
+        }
+      }
+      double merit2 = fmax(rd2, fmax(rp_rel, (gap + dgap) / fmax(1.0, fabs(fval))));
+      if (merit2 <= opts.tol_loose && merit2 < saved_merit) {
+        for (int j = 0; j < n; ++j) xs[j] = x[j];
+        for (int i = 0; i < mt; ++i) lams[i] = i < n ? tmp[i] : (w.hl[i] ? zl[i] : 0) - (w.hu[i] ? zu[i] : 0);
+        have_saved = 1; saved_merit = merit2;
+      }
+      if (have_saved) { flag = 2; break; }
     } else if (have_saved && merit > opts.tol_loose) {
       flag = 2; break;
     }
