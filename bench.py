@@ -127,6 +127,14 @@ def main():
                      "hbm_frac_one_pass": bytes_solve * Bl / (k_ms * 1e-3) / 8e12},
     }
 
+    # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py; rocprofv3 --pmc FETCH_SIZE
+    # and --pmc WRITE_SIZE in separate runs, gfx950 corrections applied) -- only for the workload they were measured on
+    pmc = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_kinN40_B4096.json")
+    if os.path.exists(pmc) and args.model == "kinematic" and N == 40 and Bl == 4096:
+        with open(pmc) as f:
+            res["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
+        res["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side, PMC, see profiles/round1/pmc_traffic_kinN40_B4096.json)"
+
     if rank == 0 and not args.no_cpu_baseline:
         import oracle as orc
         otr = orc.Track.load(os.path.join(ROOT, "fsae-mpc_amd", "tracks", "fsg2019.json"))

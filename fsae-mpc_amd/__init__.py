@@ -4,10 +4,10 @@ package is the host-side mirror of the reference's interfaces for that path; it 
 from . import _lib
 from ._lib import FsaempcError, default_opts, lib
 from .ltvmpc import LtvBatch, dims, ltvmpc_dynamic_curvilinear, ltvmpc_kinetmatic_curvilinear
-from .qpoases import qp_solve_batch_device, qpOASES
+from .qpoases import qp_solve_batch_device, qpOASES, qpOASES_sequence
 from .synthetic import DYNAMIC, KINEMATIC, instances, reference_live
 from .tracks import Track
 
 __all__ = ["FsaempcError", "default_opts", "lib", "LtvBatch", "dims", "ltvmpc_dynamic_curvilinear",
-           "ltvmpc_kinetmatic_curvilinear", "qp_solve_batch_device", "qpOASES", "DYNAMIC", "KINEMATIC",
+           "ltvmpc_kinetmatic_curvilinear", "qp_solve_batch_device", "qpOASES", "qpOASES_sequence", "DYNAMIC", "KINEMATIC",
            "instances", "reference_live", "Track"]

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <vector>
 #include "fsaempc.h"
 #include "qp_solver.h"
 #include "ltv_build.h"
@@ -111,6 +112,62 @@ int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc, const double* H, const d
   }
   (void)hipFree(dev);
   return rc;
+}
+
+// ---- qpOASES_sequence handles (qpOASES_sequence.m:23-78) ----
+namespace {
+struct SeqQP { int nV = 0, nC = 0; std::vector<double> H, A; bool used = false; };
+std::mutex g_seq_mu;
+std::vector<SeqQP> g_seq;   // handle = index + 1 (the MEX gateway also hands out small integers)
+SeqQP* seq_get(int handle) { return (handle >= 1 && handle <= (int)g_seq.size() && g_seq[handle - 1].used) ? &g_seq[handle - 1] : nullptr; }
+int seq_solve(SeqQP* q, const double* g, const double* lb, const double* ub, const double* lbA, const double* ubA, int k,
+              const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter, double* lambda) {
+  fsaempc_qp_desc d{q->nV, q->nC, k, 1};
+  return fsaempc_qp_solve_batch(&d, q->H.data(), g, q->nC ? q->A.data() : nullptr, lb, ub, lbA, ubA, opts, x, fval, exitflag, iter, lambda);
+}
+}  // namespace
+
+int fsaempc_seq_init(int nV, int nC, const double* H, const double* g, const double* A, const double* lb, const double* ub,
+                     const double* lbA, const double* ubA, int k, const fsaempc_qp_opts* opts, int* handle,
+                     double* x, double* fval, int* exitflag, int* iter, double* lambda) {
+  if (!handle || !H || nV <= 0 || nC < 0 || k <= 0 || (nC > 0 && !A)) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'i'");
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  int idx = -1;
+  for (size_t i = 0; i < g_seq.size(); ++i) if (!g_seq[i].used) { idx = (int)i; break; }
+  if (idx < 0) { g_seq.emplace_back(); idx = (int)g_seq.size() - 1; }
+  SeqQP& q = g_seq[idx];
+  q.nV = nV; q.nC = nC; q.H.assign(H, H + (size_t)nV * nV); q.A.assign(A ? A : H, (A ? A : H) + (size_t)nC * nV); q.used = true;
+  *handle = idx + 1;
+  int rc = seq_solve(&q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda);
+  if (rc != 0) { q.used = false; *handle = 0; }
+  return rc;
+}
+int fsaempc_seq_hotstart(int handle, int nV, int nC, const double* g, const double* lb, const double* ub, const double* lbA,
+                         const double* ubA, int k, const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter, double* lambda) {
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  SeqQP* q = seq_get(handle);
+  if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");
+  if (nV != q->nV || nC != q->nC) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): QP dimensions must be constant during a sequence!");
+  return seq_solve(q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda);
+}
+int fsaempc_seq_hotstart_matrices(int handle, int nV, int nC, const double* H, const double* g, const double* A, const double* lb,
+                                  const double* ub, const double* lbA, const double* ubA, int k, const fsaempc_qp_opts* opts,
+                                  double* x, double* fval, int* exitflag, int* iter, double* lambda) {
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  SeqQP* q = seq_get(handle);
+  if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");
+  if (nV != q->nV || nC != q->nC) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): QP dimensions must be constant during a sequence!");
+  if (!H || (nC > 0 && !A)) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'm'");
+  q->H.assign(H, H + (size_t)nV * nV);
+  if (nC) q->A.assign(A, A + (size_t)nC * nV);
+  return seq_solve(q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda);
+}
+int fsaempc_seq_cleanup(int handle) {
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  SeqQP* q = seq_get(handle);
+  if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");   // what main.m:193 would hit with QP == 0
+  q->used = false; q->H.clear(); q->A.clear();
+  return 0;
 }
 
 int fsaempc_ltv_nx(int model) { return model == FSAEMPC_MODEL_KINEMATIC ? 5 : 7; }

@@ -108,3 +108,54 @@ def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=F
                                              C.c_longlong(workspace.numel() * 8), C.c_void_p(st))
     check(rc, "fsaempc_qp_solve_batch_device")
     return dict(x=x, fval=fval, exitflag=flag, iter=it, lam=lam, workspace=workspace)
+
+
+def qpOASES_sequence(cmd, *args, options=None):
+    """Mirror of qpOASES_sequence (optimizers/matlab/qpOASES/qpOASES_sequence.m):
+      [QP,x,fval,exitflag,iter,lambda] = qpOASES_sequence('i', H,g,A,lb,ub,lbA,ubA)     (:23)
+      [x,fval,exitflag,iter,lambda]    = qpOASES_sequence('h', QP, g,lb,ub,lbA,ubA)     (:39)
+      [x,fval,exitflag,iter,lambda]    = qpOASES_sequence('m', QP, H,g,A,lb,ub,lbA,ubA) (:51)
+                                         qpOASES_sequence('c', QP)                      (:76)
+    The handle remembers the dimensions (and H, A for 'h'); every call is a cold solve in this round."""
+    L = lib()
+    opts = options if options is not None else default_opts()
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    colmajor = lambda M: np.ascontiguousarray(np.asarray(M, dtype=np.float64).T)
+
+    def outs(nV, nC):
+        return np.zeros(nV), np.zeros(1), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(nV + nC)
+
+    if cmd == "i":
+        H, g, A, lb, ub, lbA, ubA = args
+        H = np.asarray(H, dtype=np.float64); A = np.asarray(A, dtype=np.float64).reshape(-1, H.shape[0])
+        nV, nC = H.shape[0], A.shape[0]
+        x, fv, fl, it, lam = outs(nV, nC)
+        h = C.c_int(0)
+        check(L.fsaempc_seq_init(nV, nC, p(colmajor(H)), p(f(g)), p(colmajor(A)), p(f(lb)), p(f(ub)), p(f(lbA)), p(f(ubA)), 1,
+                                 C.byref(opts), C.byref(h), p(x), p(fv), p(fl), p(it), p(lam)), "qpOASES_sequence('i')")
+        _SEQ_DIMS[h.value] = (nV, nC)
+        return h.value, x, float(fv[0]), int(fl[0]), int(it[0]), lam
+    if cmd in ("h", "m"):
+        QP = int(args[0])
+        nV, nC = _SEQ_DIMS.get(QP, (1, 0))
+        x, fv, fl, it, lam = outs(nV, nC)
+        if cmd == "h":
+            g, lb, ub, lbA, ubA = args[1:]
+            rc = L.fsaempc_seq_hotstart(QP, nV, nC, p(f(g)), p(f(lb)), p(f(ub)), p(f(lbA)), p(f(ubA)), 1, C.byref(opts),
+                                        p(x), p(fv), p(fl), p(it), p(lam))
+        else:
+            H, g, A, lb, ub, lbA, ubA = args[1:]
+            H = np.asarray(H, dtype=np.float64); A = np.asarray(A, dtype=np.float64).reshape(-1, H.shape[0])
+            rc = L.fsaempc_seq_hotstart_matrices(QP, H.shape[0], A.shape[0], p(colmajor(H)), p(f(g)), p(colmajor(A)), p(f(lb)), p(f(ub)),
+                                                 p(f(lbA)), p(f(ubA)), 1, C.byref(opts), p(x), p(fv), p(fl), p(it), p(lam))
+        check(rc, "qpOASES_sequence('%s')" % cmd)
+        return x, float(fv[0]), int(fl[0]), int(it[0]), lam
+    if cmd == "c":
+        check(L.fsaempc_seq_cleanup(int(args[0])), "qpOASES_sequence('c')")
+        _SEQ_DIMS.pop(int(args[0]), None)
+        return None
+    raise ValueError("ERROR (qpOASES): unknown command '%s'" % cmd)
+
+
+_SEQ_DIMS = {}

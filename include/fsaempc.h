@@ -86,6 +86,27 @@ int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc,
                            const fsaempc_qp_opts* opts,
                            double* x, double* fval, int* exitflag, int* iter, double* lambda);
 
+/* ---- qpOASES_sequence: handle-based solves of a sequence of QPs -------------------------------
+ * Replaces optimizers/matlab/qpOASES/qpOASES_sequence.m:23 ('i'), :39 ('h'), :51 ('m'), :76 ('c')
+ * (commented call sites ltvmpc_kinetmatic_curvilinear.m:44-50, live cleanup main.m:193).  Host pointers,
+ * one QP per call (k columns of g/lb/ub/lbA/ubA => k QPs, as in qpOASES.m:65-67).  The handle keeps H and A
+ * resident on the device between calls.  This round every call is a cold interior-point solve (the results are
+ * those of qpOASES hot starts; the previous iterate is not yet used as a warm start).
+ * Errors mirror the gateway: unknown handle => FSAEMPC_ERR_ARG "Invalid handle to QP instance!", changed
+ * dimensions => FSAEMPC_ERR_ARG "QP dimensions must be constant during a sequence!". */
+int fsaempc_seq_init(int nV, int nC, const double* H, const double* g, const double* A,
+                     const double* lb, const double* ub, const double* lbA, const double* ubA, int k,
+                     const fsaempc_qp_opts* opts, int* handle,
+                     double* x, double* fval, int* exitflag, int* iter, double* lambda);      /* 'i' */
+int fsaempc_seq_hotstart(int handle, int nV, int nC, const double* g, const double* lb, const double* ub,
+                         const double* lbA, const double* ubA, int k, const fsaempc_qp_opts* opts,
+                         double* x, double* fval, int* exitflag, int* iter, double* lambda);  /* 'h' */
+int fsaempc_seq_hotstart_matrices(int handle, int nV, int nC, const double* H, const double* g, const double* A,
+                                  const double* lb, const double* ub, const double* lbA, const double* ubA, int k,
+                                  const fsaempc_qp_opts* opts,
+                                  double* x, double* fval, int* exitflag, int* iter, double* lambda);  /* 'm' */
+int fsaempc_seq_cleanup(int handle);                                                         /* 'c' */
+
 /* ---- LTV-MPC step (QP construction + solve + post-solve) ---------------------------------- */
 
 /* Track spline table: the `kappa` closure of main.m:18 as data.  xP,yP: M x 4 column-major. */

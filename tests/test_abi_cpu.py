@@ -44,6 +44,15 @@ def test_gateway_argument_validation():
         fm.qpOASES(H, g, [0, 0])
 
 
+def test_sequence_handle_errors():
+    import fsae_mpc_amd as fm
+    # main.m:193 calls qpOASES_sequence('c', QP) with QP == 0: the gateway answers "Invalid handle to QP instance!"
+    with pytest.raises(fm.FsaempcError, match="Invalid handle"):
+        fm.qpOASES_sequence("c", 0)
+    with pytest.raises(fm.FsaempcError, match="Invalid handle"):
+        fm.qpOASES_sequence("h", 7, [0.0], [0.0], [1.0], [], [])
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():

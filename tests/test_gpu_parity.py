@@ -218,6 +218,29 @@ def test_full_size_config2_properties(fm, torch_, orc):
     assert torch.equal(c["x"], a["x"][sl])
 
 
+def test_sequence_api(fm, orc, otrack):
+    """qpOASES_sequence 'i' / 'm' / 'h' / 'c' on three consecutive LTV-MPC QPs (the commented call pattern of
+    ltvmpc_kinetmatic_curvilinear.m:44-50) against the oracle."""
+    N = 10
+    x0, xl, ul, xr = orc.synth_instances(0, N, 0.05, otrack.L, 20190, [11, 12, 13])
+    qs = [orc.build_qp(0, otrack, N, 0.05, x0[b], xr[b].T, xl[b].T, ul[b].T) for b in range(3)]
+    args = lambda q: (q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"])
+    ref = [orc.qp_solve(*args(q)) for q in qs]
+    QP, x, f, fl, it, lam = fm.qpOASES_sequence("i", *args(qs[0]))
+    assert QP >= 1 and fl == 0 and abs(f - ref[0][1]) <= FVAL_TOL * max(1, abs(ref[0][1]))
+    x, f, fl, it, lam = fm.qpOASES_sequence("m", QP, *args(qs[1]))
+    assert fl == 0 and abs(f - ref[1][1]) <= FVAL_TOL * max(1, abs(ref[1][1])) and orc.qp_kkt(*args(qs[1]), x, lam)[0] <= KKT_TOL
+    q2 = dict(qs[1]); q2["g"] = qs[1]["g"] * 1.01     # 'h': same H and A, new vectors
+    x, f, fl, it, lam = fm.qpOASES_sequence("h", QP, q2["g"], q2["lb"], q2["ub"], q2["lbA"], q2["ubA"])
+    xo, fo, flo, _, _ = orc.qp_solve(*args(q2))
+    assert fl == 0 and abs(f - fo) <= FVAL_TOL * max(1, abs(fo))
+    with pytest.raises(fm.FsaempcError, match="dimensions must be constant"):
+        fm.qpOASES_sequence("m", QP, np.eye(3), np.zeros(3), np.zeros((1, 3)), np.zeros(3), np.ones(3), [0.0], [1.0])
+    fm.qpOASES_sequence("c", QP)
+    with pytest.raises(fm.FsaempcError, match="Invalid handle"):
+        fm.qpOASES_sequence("c", QP)
+
+
 def test_edge_cases(fm, torch_):
     torch = torch_
     # nV = 1, nC = 0 ; empty batch ; nV = 128 (FSAEMPC_MAX_NV) with random SPD data ; ragged tile sizes
