@@ -1138,8 +1138,12 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       if (mu > 0 && sigma < mu_floor / mu) sigma = fmin(1.0, mu_floor / mu);
     }
     const double smu = sigma * mu;
+    // the second-order term is dropped when the affine step is tiny (it then models nothing and makes the iteration
+    // cycle on low-speed instances); this also saves the corrector solve and pass 3 for that iteration
+    const double cw = a_aff >= 0.05 ? 1.0 : 0.0;
     __syncthreads();
     STAMP(8);
+    if (cw != 0.0) {
     // ================= corrector: P1 = A' w_cor came out of the fused pass 2 =================
     STAMP(9);
     for (int h = 0; h < 2; ++h) {
@@ -1169,6 +1173,11 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aW2[(J + jb) * 64 + lane] = i < n ? DX[i] : 0.0; }
     }
     STAMP(11);
+    } else {   // no corrector this iteration
+      for (int i = lane; i < k.np; i += 64) DX[i] = 0.0;
+      for (int js = 0; js < JT; ++js) aW2[js * 64 + lane] = 0.0;
+      __syncthreads();
+    }
     // full direction dx = dxa + smu*dxc + dxcor ; dv likewise
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
@@ -1182,7 +1191,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       if (js < JT) aVC[r.ix] = dv;  // keep the full G dx for the update
       if (hl) {
         const double dta = r.va + r.rpl, dza = -r.zl - (r.zl / r.tl) * dta;
-        const double cl = smu - dta * dza;
+        const double cl = smu - cw * dta * dza;
         const double dt = dv + r.rpl, dz = -r.zl + cl / r.tl - (r.zl / r.tl) * dt;
         if (dt < 0 && -r.tl / dt < amax) { amax = -r.tl / dt; bp = r.tl; bdp = dt; bd = r.zl; bdd = dz; }
         if (dz < 0 && -r.zl / dz < amax) { amax = -r.zl / dz; bp = r.zl; bdp = dz; bd = r.tl; bdd = dt; }
@@ -1190,7 +1199,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       }
       if (hu) {
         const double dta = -r.va + r.rpu, dza = -r.zu - (r.zu / r.tu) * dta;
-        const double cu = smu - dta * dza;
+        const double cu = smu - cw * dta * dza;
         const double dt = -dv + r.rpu, dz = -r.zu + cu / r.tu - (r.zu / r.tu) * dt;
         if (dt < 0 && -r.tu / dt < amax) { amax = -r.tu / dt; bp = r.tu; bdp = dt; bd = r.zu; bdd = dz; }
         if (dz < 0 && -r.zu / dz < amax) { amax = -r.zu / dz; bp = r.zu; bdp = dz; bd = r.tu; bdd = dt; }
@@ -1223,7 +1232,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       double tl = r.tl, zl = r.zl, tu = r.tu, zu = r.zu;
       if (hl) {
         const double dta = r.va + r.rpl, dza = -zl - (zl / tl) * dta;
-        const double cl = smu - dta * dza;
+        const double cl = smu - cw * dta * dza;
         const double dt = dv + r.rpl, dz = -zl + cl / tl - (zl / tl) * dt;
         tl += alpha * dt; zl += alpha * dz;
         aTL[r.ix] = tl; aZL[r.ix] = zl;
@@ -1231,7 +1240,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       }
       if (hu) {
         const double dta = -r.va + r.rpu, dza = -zu - (zu / tu) * dta;
-        const double cu = smu - dta * dza;
+        const double cu = smu - cw * dta * dza;
         const double dt = -dv + r.rpu, dz = -zu + cu / tu - (zu / tu) * dt;
         tu += alpha * dt; zu += alpha * dz;
         aTU[r.ix] = tu; aZU[r.ix] = zu;

@@ -485,8 +485,11 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
     }
     /* corrector */
     for (int i = 0; i < mt; ++i) {
-      cl[i] = w.hl[i] ? sigma * mu - (opts.corrector ? dtl[i] * dzl[i] : 0) : 0;
-      cu[i] = w.hu[i] ? sigma * mu - (opts.corrector ? dtu[i] * dzu[i] : 0) : 0;
+      /* the second-order term is dropped when the affine step is tiny (it then models nothing and makes the
+       * iteration cycle on low-speed instances) */
+      const double cw = (opts.corrector && alpha_aff >= 0.05) ? 1.0 : 0.0;
+      cl[i] = w.hl[i] ? sigma * mu - cw * dtl[i] * dzl[i] : 0;
+      cu[i] = w.hu[i] ? sigma * mu - cw * dtu[i] * dzu[i] : 0;
       wv[i] = (w.hl[i] ? cl[i] / tl[i] : 0) - (w.hu[i] ? cu[i] / tu[i] : 0);
     }
     apply_Gt(&w, wv, tmp);
