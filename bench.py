@@ -121,7 +121,7 @@ def main():
                    "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "solved_total": int(solved_total), "tol_kkt": 1e-8,
                    "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,
                    "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
-        "roofline": {"bound": "mfma", "kernel": "qp_solve_kernel<%d>" % ((nV + 15) // 16), "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "qp_solve_kernel<%d, %d>" % ((nV // 16, 1 if nV % 16 == 1 else 4) if (nV >= 16 and 1 <= nV % 16 <= 4) else ((nV + 15) // 16, 0)), "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "flops_per_launch": flops_launch, "algorithmic_bytes_per_solve": bytes_solve,
                      "hbm_frac_one_pass": bytes_solve * Bl / (k_ms * 1e-3) / 8e12},
