@@ -11,14 +11,14 @@ EXPORTS = [
     "fsaempc_qp_default_opts", "fsaempc_qp_workspace_bytes", "fsaempc_qp_solve_batch_device", "fsaempc_qp_solve_batch",
     "fsaempc_ltv_nx", "fsaempc_ltv_nV", "fsaempc_ltv_nC", "fsaempc_ltv_build_qp_batch_device",
     "fsaempc_ltv_workspace_bytes", "fsaempc_ltv_step_batch_device", "fsaempc_last_error", "fsaempc_selftest_mfma",
-    "fsaempc_debug_set_dump", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
+    "fsaempc_debug_set_dump", "fsaempc_debug_set_polished", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
     "fsaempc_seq_init", "fsaempc_seq_hotstart", "fsaempc_seq_hotstart_matrices", "fsaempc_seq_cleanup",
 ]
 
 
 class QpOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("tol_loose", C.c_double), ("tol_x", C.c_double), ("inf_bound", C.c_double),
-                ("max_iter", C.c_int), ("reserved", C.c_int)]
+                ("max_iter", C.c_int), ("polish", C.c_int)]
 
 
 class QpDesc(C.Structure):
@@ -56,6 +56,7 @@ def lib():
         L.fsaempc_ltv_build_qp_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [vp] * 7 + [vp] * 3 + [vp]
         L.fsaempc_ltv_step_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [C.POINTER(QpOpts)] + [vp] * 6 + [vp, ll, vp]
         L.fsaempc_debug_set_dump.argtypes = [vp, C.c_int]
+        L.fsaempc_debug_set_polished.argtypes = [vp]
         _LIB = L
     return _LIB
 

@@ -13,7 +13,7 @@
 
 namespace {
 thread_local char g_err[512] = "";
-double* g_dump = nullptr; int g_dump_stage = 0, g_dump_iter = 0;
+double* g_dump = nullptr; int g_dump_stage = 0, g_dump_iter = 0; int* g_polished = nullptr;
 bool g_timing = false; hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 
 int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); return code; }
@@ -31,7 +31,7 @@ const char* fsaempc_last_error(void) { return g_err; }
 
 void fsaempc_qp_default_opts(fsaempc_qp_opts* o) {
   if (!o) return;
-  o->tol = 1e-8; o->tol_loose = 1e-6; o->tol_x = 1e-7; o->inf_bound = 1e9; o->max_iter = 100; o->reserved = 0;
+  o->tol = 1e-8; o->tol_loose = 1e-6; o->tol_x = 1e-7; o->inf_bound = 1e9; o->max_iter = 100; o->polish = 1;
 }
 
 long long fsaempc_qp_workspace_bytes(const fsaempc_qp_desc* desc) {
@@ -57,7 +57,7 @@ int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc, const double* H, 
   if (P.d.lds_solve > 160 * 1024 || P.d.lds_prep > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of this kernel generation");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
-  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter;
+  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = g_polished;
   P.shared_HA = desc->shared_HA;
   P.dump = g_dump; P.dump_stage = g_dump_stage & 0xff; P.dump_iter = g_dump_stage >> 8;
   hipError_t e;
@@ -258,6 +258,7 @@ int fsaempc_selftest_mfma(void) {
 }
 
 int fsaempc_debug_set_dump(double* out, int stage) { g_dump = out; g_dump_stage = stage; return 0; }
+int fsaempc_debug_set_polished(int* out) { g_polished = out; return 0; }
 
 int fsaempc_qp_set_timing(int enable) {
   if (enable && !g_ev[0]) {

@@ -22,7 +22,8 @@ struct QpParams {
   double *x, *fval, *lambda;
   int *exitflag, *iter;
   double tol, tol_loose, tol_x, inf_bound;
-  int max_iter, shared_HA;
+  int max_iter, shared_HA, polish;
+  int* polished;   // optional per-instance output: 1 if the active-set polish was accepted
   double* dump; int dump_stage, dump_iter;
 };
 

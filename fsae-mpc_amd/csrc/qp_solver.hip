@@ -385,11 +385,11 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
 // direction; as soon as a row's va = a_r' dxa is reduced, the second-order weight
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
-template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor) {
+template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor, double* Pcor2 = nullptr) {
   constexpr int PF = 2;   // pairs of k-steps in flight (little compute per step => latency bound otherwise)
   constexpr int NBB = NB > 0 ? NB : 1;
   const int JS = k.J * 64, Kq2 = (k.Kq + 1) >> 1;
-  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], cq[PF][2][6 + NBB];
+  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], pd[FUSE >= 2 ? T : 1], pdb[NBB], cq[PF][2][6 + NBB];
   v2d bq[PF][T];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e) {
@@ -401,7 +401,9 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
 #pragma unroll
   for (int t = 0; t < T; ++t) pc[t] = 0.0;
 #pragma unroll
-  for (int f = 0; f < NBB; ++f) pcb[f] = 0.0;
+  for (int f = 0; f < NBB; ++f) { pcb[f] = 0.0; pdb[f] = 0.0; }
+#pragma unroll
+  for (int t = 0; t < (FUSE >= 2 ? T : 1); ++t) pd[t] = 0.0;
   const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
   const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
   auto issue = [&](int u, int s2) {
@@ -412,7 +414,8 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
       const int s = 2 * s2 + h;
       if (s < k.Kq) {
         const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-        if (FUSE) { cq[u][h][0] = CA1[ri]; cq[u][h][1] = CB1[ri]; cq[u][h][2] = CC1[ri]; cq[u][h][3] = CA2[ri]; cq[u][h][4] = CB2[ri]; cq[u][h][5] = CC2[ri]; }
+        if (FUSE == 1) { cq[u][h][0] = CA1[ri]; cq[u][h][1] = CB1[ri]; cq[u][h][2] = CC1[ri]; cq[u][h][3] = CA2[ri]; cq[u][h][4] = CB2[ri]; cq[u][h][5] = CC2[ri]; }
+        if (FUSE >= 2) { cq[u][h][0] = CB1[ri]; cq[u][h][1] = CA1[ri]; cq[u][h][2] = CC1[ri]; }   // polish: rho*act, target b, multiplier y
 #pragma unroll
         for (int f = 0; f < NB; ++f) cq[u][h][6 + f] = k.Ab[(size_t)f * JS + ri];
       }
@@ -428,9 +431,9 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
       for (int e = 0; e < 6 + NBB; ++e) cq[u][h][e] = 0.0;
     if (u < Kq2) issue(u, u);
   }
-  double keep[NVEC];
+  double keep[NVEC + 1];   // last entry: the updated multiplier of the polish modes (written to rout[NVEC])
 #pragma unroll
-  for (int e = 0; e < NVEC; ++e) keep[e] = 0.0;
+  for (int e = 0; e < NVEC + 1; ++e) keep[e] = 0.0;
   for (int s0 = 0; s0 < Kq2; s0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -459,7 +462,16 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
 #pragma unroll
               for (int f = 0; f < NB; ++f) dsum = fma(cf[h][6 + f], vb[e][f], dsum);
               if (k.c == cc) keep[e] = dsum;
-              if (FUSE && e == 0) {
+              if (FUSE >= 2 && e == 0) {   // polish: pen = rho*act*(v - b), y^ = y - pen; accumulate A~'y^ and A~'pen
+                const double pen = cf[h][0] * (dsum - cf[h][1]);
+                const double ynew = cf[h][2] - pen;
+                if (k.c == cc) keep[NVEC] = ynew;
+#pragma unroll
+                for (int t = 0; t < T; ++t) { pc[t] = fma(ynew, bc[h][t], pc[t]); pd[t] = fma(pen, bc[h][t], pd[t]); }
+#pragma unroll
+                for (int f = 0; f < NB; ++f) { pcb[f] = fma(ynew, cf[h][6 + f], pcb[f]); pdb[f] = fma(pen, cf[h][6 + f], pdb[f]); }
+              }
+              if (FUSE == 1 && e == 0) {
                 const double dl_ = dsum + cf[h][0], du_ = cf[h][3] - dsum;
                 const double w = dl_ * fma(cf[h][2], dl_, cf[h][1]) - du_ * fma(cf[h][5], du_, cf[h][4]);
 #pragma unroll
@@ -472,6 +484,7 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
               const int js = s >> 4;
 #pragma unroll
               for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
+              if (FUSE >= 2) { rout[NVEC][js * 64 + k.lane] = keep[NVEC]; keep[NVEC] = 0.0; }
             }
           }
         }
@@ -486,6 +499,15 @@ template <int T, int NB, int NVEC, bool FUSE> DEVINL void pass_Av(const Ctx& k, 
     }
 #pragma unroll
     for (int f = 0; f < NB; ++f) { const double pv = q_sum(pcb[f]); if (k.lane == 0) Pcor[k.nc + f] = pv; }
+  }
+  if (FUSE >= 2) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double pv = q_sum(pd[t]);
+      if (k.q == 0) Pcor2[16 * t + k.c] = pv;
+    }
+#pragma unroll
+    for (int f = 0; f < NB; ++f) { const double pv = q_sum(pdb[f]); if (k.lane == 0) Pcor2[k.nc + f] = pv; }
   }
 }
 
@@ -742,19 +764,19 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #define aRPU rowp(k, R_RPU)
 
   // Hx = H~ x: core through the tile grid, border columns (full-length vectors Hb[b]) on the VALU
-  auto hx_full = [&]() {
-    hx_tiles<T>(k, X, HX);
+  auto hx_full = [&](const double* XV) {
+    hx_tiles<T>(k, XV, HX);
     if (NB > 0) {
       __syncthreads();
       double xb[NBB], sb[NBB];
 #pragma unroll
-      for (int e = 0; e < NB; ++e) { xb[e] = X[nc + e]; sb[e] = 0.0; }
+      for (int e = 0; e < NB; ++e) { xb[e] = XV[nc + e]; sb[e] = 0.0; }
       for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
         if (i < n) {
           double add = 0.0;
 #pragma unroll
-          for (int e = 0; e < NB; ++e) { const double hbi = k.Hb[(size_t)e * k.np + i]; add = fma(hbi, xb[e], add); sb[e] = fma(hbi, X[i], sb[e]); }
+          for (int e = 0; e < NB; ++e) { const double hbi = k.Hb[(size_t)e * k.np + i]; add = fma(hbi, xb[e], add); sb[e] = fma(hbi, XV[i], sb[e]); }
           if (i < nc) HX[i] += add;
         }
       }
@@ -794,14 +816,14 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   __syncthreads();
 
   STAMP_DECL
-  int flag = 1, it = 0;
+  int flag = 1, it = 0, flag_polished = 0;
   double fval_s = 0.0;
   if (infeas) { flag = -2; }
 
   // ---- v = G x ----
   {
     const double* vin[1] = {X}; double* rout[1] = {aV};
-    pass_Av<T, NB, 1, false>(k, vin, rout, nullptr);
+    pass_Av<T, NB, 1, 0>(k, vin, rout, nullptr);
     for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aV[(J + jb) * 64 + lane] = i < n ? X[i] : 0.0; }
   }
   // ---- initial slacks / multipliers in the equilibrated problem: t = max(resid, T0), z = Z0 (a scan over the
@@ -821,7 +843,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   __syncthreads();
   // bound multipliers absorb the initial dual residual r = Hx + g - A'(zl - zu)
   {
-    hx_full();
+    hx_full(X);
     pass_Atw<T, NB>(k, aW3, P3);
     __syncthreads();
     for (int jb = 0; jb < k.JB; ++jb) {
@@ -871,6 +893,151 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   };
   double gap = 0.0, rp_rel = 0.0;   // carried across iterations (produced by the update sweep)
 
+  v4d acc[NT];          // upper tiles of M, then of its Cholesky factor U
+  v4d rh[T];            // right-hand-side tile column
+  double Ubb[NBB][NBB]; // Cholesky factor of the border Schur complement (wave-uniform scalars)
+  // border part of a solve: R holds y_c = U^-T b_c (core) and b_b (border); leaves the border solution in R[nc+e]
+  // and y_c - sum_e u_e x_e in the core, ready for the backward sweep
+  auto border_solve = [&](double* R) {
+    if (NB > 0) {
+      double yb[NBB], xb[NBB];
+#pragma unroll
+      for (int e = 0; e < NB; ++e) {
+        double dsum = 0.0;
+        for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < nc) dsum = fma(MB[e * k.np + i], R[i], dsum); }
+        double tt = R[nc + e] - wave_sum(dsum);
+#pragma unroll
+        for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * yb[g2];
+        yb[e] = tt / Ubb[e][e];
+      }
+#pragma unroll
+      for (int e = NB - 1; e >= 0; --e) {
+        double tt = yb[e];
+#pragma unroll
+        for (int f = e + 1; f < NB; ++f) tt -= Ubb[e][f] * xb[f];
+        xb[e] = tt / Ubb[e][e];
+      }
+      __syncthreads();
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < nc) {
+          double r = R[i];
+#pragma unroll
+          for (int e = 0; e < NB; ++e) r = fma(-MB[e * k.np + i], xb[e], r);
+          R[i] = r;
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) R[nc + e] = xb[e];
+      }
+      __syncthreads();
+    }
+  };
+  // M = (acc from pass 1) + diag(aD on the variable rows), border columns = H~ border + A'DA border (MB); factorise in
+  // registers and solve for the two right-hand sides in R1, R2 (in place).  Returns 1 on a non-finite pivot.
+  auto factor_solve2 = [&](int it_now) -> int {
+    double dmax_l = 0;
+#pragma unroll
+    for (int K = 0; K < T; ++K) {
+      const int i = 16 * K + k.c;                       // diagonal element of tile (K,K) lives on lane c with q = c&3, reg c>>2
+      const int ix = (J + (i >> 6)) * 64 + (i & 63);
+      const double dadd = i < n ? aD[ix] : 1.0;         // padded indices get a unit diagonal
+      const bool mine = (k.q == (k.c & 3));
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (mine && p == (k.c >> 2)) { acc[Tri<T>::idx(K, K)][p] += dadd; dmax_l = fmax(dmax_l, acc[Tri<T>::idx(K, K)][p]); }
+    }
+    if (NB > 0) {
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < k.np) {
+          const int ix = (J + (i >> 6)) * 64 + (i & 63);
+#pragma unroll
+          for (int e = 0; e < NB; ++e) {   // border column e of M: H~ column + A'DA column (+ its variable-bound weight on the diagonal)
+            double v = i < n ? k.Hb[(size_t)e * k.np + i] + MB[e * k.np + i] : 0.0;
+            if (i == nc + e) { v += e < nb ? aD[ix] : 1.0; dmax_l = fmax(dmax_l, v); }
+            MB[e * k.np + i] = v;
+          }
+        }
+      }
+    }
+    const double dmax = wave_max(dmax_l);
+    __syncthreads();
+    if (P.dump && b == 0 && P.dump_stage == 1 && it_now == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
+#pragma unroll
+      for (int I = 0; I < T; ++I)
+#pragma unroll
+        for (int Jt = I; Jt < T; ++Jt)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int r = 16 * I + k.q + 4 * p, cc = 16 * Jt + k.c;
+            if (r < n && cc < n) { P.dump[r * n + cc] = acc[Tri<T>::idx(I, Jt)][p]; if (I != Jt || cc >= r) P.dump[cc * n + r] = acc[Tri<T>::idx(I, Jt)][p]; }
+          }
+      for (int e = 0; e < nb; ++e)
+        for (int i = lane; i < n; i += 64) { P.dump[i * n + nc + e] = MB[e * k.np + i]; P.dump[(nc + e) * n + i] = MB[e * k.np + i]; }
+      for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
+    }
+    {
+      const double* vin[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
+      rhs_load<T, 2 + NB>(k, rh, vin);
+    }
+    int fbad = reg_factor<T>(k, acc, YL, rh, 1e-30 * dmax);
+    if (NB > 0) {   // bordered factor: u_e = U^-T m_e came out of the forward sweep; S = M_bb - u'u is factorised as scalars
+      double* vout[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
+      rhs_store<T, 2 + NB>(k, rh, vout);
+      __syncthreads();
+      double S[NBB][NBB];
+#pragma unroll
+      for (int e = 0; e < NB; ++e)
+#pragma unroll
+        for (int f = e; f < NB; ++f) {
+          double dsum = 0.0;
+          for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < nc) dsum = fma(MB[e * k.np + i], MB[f * k.np + i], dsum); }
+          S[e][f] = MB[e * k.np + nc + f] - wave_sum(dsum);
+        }
+#pragma unroll
+      for (int e = 0; e < NB; ++e) {
+        double dd = S[e][e];
+#pragma unroll
+        for (int g2 = 0; g2 < e; ++g2) dd -= Ubb[g2][e] * Ubb[g2][e];
+        if (!(dd > 1e-30 * dmax)) { if (!(fabs(dd) < INFINITY)) fbad = 1; dd = 1e-30 * dmax; }
+        Ubb[e][e] = sqrt(dd);
+#pragma unroll
+        for (int f = e + 1; f < NB; ++f) {
+          double tt = S[e][f];
+#pragma unroll
+          for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * Ubb[g2][f];
+          Ubb[e][f] = tt / Ubb[e][e];
+        }
+      }
+    }
+    if (fbad) return 1;
+    if (NB > 0) {
+      border_solve(R1); border_solve(R2);
+      const double* vin[2] = {R1, R2};
+      rhs_load<T, 2>(k, rh, vin);
+    }
+    reg_backward<T>(k, acc, YL, rh, SCR);
+    { double* vout[2] = {R1, R2}; rhs_store<T, 2>(k, rh, vout); }
+    __syncthreads();
+    return 0;
+  };
+  // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place)
+  auto solve1 = [&](double* V) {
+    const double* vin[1] = {V}; double* vout[1] = {V};
+    rhs_load<T, 1>(k, rh, vin);
+    reg_forward<T>(k, acc, YL, rh);
+    if (NB > 0) {
+      rhs_store<T, 1>(k, rh, vout);
+      __syncthreads();
+      border_solve(V);
+      rhs_load<T, 1>(k, rh, vin);
+    }
+    reg_backward<T>(k, acc, YL, rh, SCR);
+    rhs_store<T, 1>(k, rh, vout);
+  };
+
   STAMP(0);
   for (it = 0; flag == 1; ++it) {
     // ================= row phase 1: residuals, weights (only on entry; afterwards fused into the update sweep) =================
@@ -888,9 +1055,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 
     STAMP(1);
     // ================= pass 1: M = H + A'DA (MFMA), p1, p2, p3; Hx =================
-    hx_full();
+    hx_full(X);
     STAMP(2);
-    v4d acc[NT];
     acc_init<T>(k, acc);
     pass_syrk<T, NB>(k, acc, P1, P2, P3, MB);
     __syncthreads();
@@ -950,132 +1116,16 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     if (merit < 0.9 * best_res) { best_res = merit; stall = 0; } else ++stall;
 
     // ================= factorise (registers, MFMA) with the affine / centering right-hand sides riding along =================
-    double dmax_l = 0;
-#pragma unroll
-    for (int K = 0; K < T; ++K) {
-      const int i = 16 * K + k.c;                       // diagonal element of tile (K,K) lives on lane c with q = c&3, reg c>>2
-      const int ix = (J + (i >> 6)) * 64 + (i & 63);
-      const double dadd = i < n ? aD[ix] : 1.0;         // padded indices get a unit diagonal
-      const bool mine = (k.q == (k.c & 3));
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        if (mine && p == (k.c >> 2)) { acc[Tri<T>::idx(K, K)][p] += dadd; dmax_l = fmax(dmax_l, acc[Tri<T>::idx(K, K)][p]); }
-    }
     for (int h = 0; h < 2; ++h) {
       const int i = lane + 64 * h;
       if (i < k.np) {
         const int ix = (J + (i >> 6)) * 64 + (i & 63);
         R1[i] = i < n ? -(HX[i] + G[i]) + P1[i] + aW1[ix] : 0.0;
         R2[i] = i < n ? P2[i] + aW2[ix] : 0.0;
-#pragma unroll
-        for (int e = 0; e < NB; ++e) {   // border column e of M: H~ column + A'DA column (+ its variable-bound weight on the diagonal)
-          double v = i < n ? k.Hb[(size_t)e * k.np + i] + MB[e * k.np + i] : 0.0;
-          if (i == nc + e) { v += e < nb ? aD[ix] : 1.0; dmax_l = fmax(dmax_l, v); }
-          MB[e * k.np + i] = v;
-        }
       }
-    }
-    const double dmax = wave_max(dmax_l);
-    __syncthreads();
-    if (P.dump && b == 0 && P.dump_stage == 1 && it == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
-#pragma unroll
-      for (int I = 0; I < T; ++I)
-#pragma unroll
-        for (int Jt = I; Jt < T; ++Jt)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const int r = 16 * I + k.q + 4 * p, cc = 16 * Jt + k.c;
-            if (r < n && cc < n) { P.dump[r * n + cc] = acc[Tri<T>::idx(I, Jt)][p]; if (I != Jt || cc >= r) P.dump[cc * n + r] = acc[Tri<T>::idx(I, Jt)][p]; }
-          }
-      for (int e = 0; e < nb; ++e)
-        for (int i = lane; i < n; i += 64) { P.dump[i * n + nc + e] = MB[e * k.np + i]; P.dump[(nc + e) * n + i] = MB[e * k.np + i]; }
-      for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
     }
     STAMP(4);
-    v4d rh[T];
-    double Ubb[NBB][NBB];
-    {
-      const double* vin[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
-      rhs_load<T, 2 + NB>(k, rh, vin);
-    }
-    int fbad = reg_factor<T>(k, acc, YL, rh, 1e-30 * dmax);
-    if (NB > 0) {   // bordered factor: u_e = U^-T m_e came out of the forward sweep; S = M_bb - u'u is factorised as scalars
-      double* vout[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
-      rhs_store<T, 2 + NB>(k, rh, vout);
-      __syncthreads();
-      double S[NBB][NBB];
-#pragma unroll
-      for (int e = 0; e < NB; ++e)
-#pragma unroll
-        for (int f = e; f < NB; ++f) {
-          double dsum = 0.0;
-          for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < nc) dsum = fma(MB[e * k.np + i], MB[f * k.np + i], dsum); }
-          S[e][f] = MB[e * k.np + nc + f] - wave_sum(dsum);
-        }
-#pragma unroll
-      for (int e = 0; e < NB; ++e) {
-        double dd = S[e][e];
-#pragma unroll
-        for (int g2 = 0; g2 < e; ++g2) dd -= Ubb[g2][e] * Ubb[g2][e];
-        if (!(dd > 1e-30 * dmax)) { if (!(fabs(dd) < INFINITY)) fbad = 1; dd = 1e-30 * dmax; }
-        Ubb[e][e] = sqrt(dd);
-#pragma unroll
-        for (int f = e + 1; f < NB; ++f) {
-          double tt = S[e][f];
-#pragma unroll
-          for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * Ubb[g2][f];
-          Ubb[e][f] = tt / Ubb[e][e];
-        }
-      }
-    }
-    if (fbad) { flag = (res_ok || have_saved) ? 2 : -1; break; }
-    // border part of a solve: R holds y_c = U^-T b_c (core) and b_b (border); leaves the border solution in R[nc+e]
-    // and y_c - sum_e u_e x_e in the core, ready for the backward sweep
-    auto border_solve = [&](double* R) {
-      if (NB > 0) {
-        double yb[NBB], xb[NBB];
-#pragma unroll
-        for (int e = 0; e < NB; ++e) {
-          double dsum = 0.0;
-          for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < nc) dsum = fma(MB[e * k.np + i], R[i], dsum); }
-          double tt = R[nc + e] - wave_sum(dsum);
-#pragma unroll
-          for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * yb[g2];
-          yb[e] = tt / Ubb[e][e];
-        }
-#pragma unroll
-        for (int e = NB - 1; e >= 0; --e) {
-          double tt = yb[e];
-#pragma unroll
-          for (int f = e + 1; f < NB; ++f) tt -= Ubb[e][f] * xb[f];
-          xb[e] = tt / Ubb[e][e];
-        }
-        __syncthreads();
-        for (int h = 0; h < 2; ++h) {
-          const int i = lane + 64 * h;
-          if (i < nc) {
-            double r = R[i];
-#pragma unroll
-            for (int e = 0; e < NB; ++e) r = fma(-MB[e * k.np + i], xb[e], r);
-            R[i] = r;
-          }
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int e = 0; e < NB; ++e) R[nc + e] = xb[e];
-        }
-        __syncthreads();
-      }
-    };
-    if (NB > 0) {
-      border_solve(R1); border_solve(R2);
-      const double* vin[2] = {R1, R2};
-      rhs_load<T, 2>(k, rh, vin);
-    }
-    STAMP(5);
-    reg_backward<T>(k, acc, YL, rh, SCR);
-    { double* vout[2] = {R1, R2}; rhs_store<T, 2>(k, rh, vout); }
-    __syncthreads();
+    if (factor_solve2(it)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
     STAMP(6);
     if (P.dump && b == 0 && P.dump_stage == 2 && it == P.dump_iter) {
       for (int i = lane; i < n; i += 64) { P.dump[i] = R1[i]; P.dump[n + i] = R2[i]; }
@@ -1094,7 +1144,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     // ================= pass 2: va = G dxa, vc = G dxc =================
     {
       const double* vin[2] = {R1, R2}; double* rout[2] = {aVA, aVC};
-      pass_Av<T, NB, 2, true>(k, vin, rout, P1);   // fused: P1 = A~' w_cor
+      pass_Av<T, NB, 2, 1>(k, vin, rout, P1);   // fused: P1 = A~' w_cor
       for (int jb = 0; jb < k.JB; ++jb) {
         const int i = jb * 64 + lane;
         aVA[(J + jb) * 64 + lane] = i < n ? R1[i] : 0.0;
@@ -1151,25 +1201,13 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       if (i < k.np) { const int ix = (J + (i >> 6)) * 64 + (i & 63); DX[i] = i < n ? P1[i] + aW1[ix] : 0.0; }
     }
     __syncthreads();
-    {
-      const double* vin[1] = {DX}; double* vout[1] = {DX};
-      rhs_load<T, 1>(k, rh, vin);
-      reg_forward<T>(k, acc, YL, rh);
-      if (NB > 0) {
-        rhs_store<T, 1>(k, rh, vout);
-        __syncthreads();
-        border_solve(DX);
-        rhs_load<T, 1>(k, rh, vin);
-      }
-      reg_backward<T>(k, acc, YL, rh, SCR);
-      rhs_store<T, 1>(k, rh, vout);
-    }
+    solve1(DX);
     __syncthreads();
     STAMP(10);
     // ================= pass 4: G dx_cor =================
     {
       const double* vin[1] = {DX}; double* rout[1] = {aW2};  // W2 reused for G dx_cor
-      pass_Av<T, NB, 1, false>(k, vin, rout, nullptr);
+      pass_Av<T, NB, 1, 0>(k, vin, rout, nullptr);
       for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aW2[(J + jb) * 64 + lane] = i < n ? DX[i] : 0.0; }
     }
     STAMP(11);
@@ -1273,6 +1311,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   }
 
   // ---- outputs ----
+  const bool v_current = flag == 0;   // aV still equals G x and fval_s is the objective at x (not so after a restore)
   if (flag == 2) {  // restore the best iterate that met tol_loose
     for (int i = lane; i < k.np; i += 64) X[i] = XS[i];
     for (int js = 0; js < JT; ++js) aW3[js * 64 + lane] = LAMS[js * 64 + lane];
@@ -1286,6 +1325,113 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       aW3[ix] = (hl ? aZL[ix] : 0.0) - (hu ? aZU[ix] : 0.0);
     }
     __syncthreads();
+  }
+  // ---- polish: from the interior-point point to the vertex an active-set solver (qpOASES) stops at ----
+  // Active set W from the multipliers (side active iff |lambda| exceeds its slack), then the method of multipliers on
+  //   min 1/2 x'H x + g'x  s.t. G_W x = b_W     with one Newton step per outer iteration, in correction form:
+  //   c = G_W x - b,  y <- y - rho c,  x <- x - (H + rho G_W'G_W)^-1 (H x + g - G_W' y + rho G_W' c)
+  // (residuals come from a fresh stream over A each time, so the ill-conditioned solve only has to contract).  It
+  // reuses pass 1 (D = rho on W), the register factorisation and the fused pass-2 shape.  The result is accepted only
+  // if it is a KKT point of the full QP to round-off level; otherwise the interior-point iterate is returned.
+  if (flag == 0 && P.polish) {
+    const double rho = 1e6;
+    double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
+    if (!v_current) {
+      const double* vin[1] = {X}; double* rout[1] = {aV};
+      pass_Av<T, NB, 1, 0>(k, vin, rout, nullptr);
+      for (int jb = 0; jb < k.JB; ++jb) { const int i = jb * 64 + lane; aV[(J + jb) * 64 + lane] = i < n ? X[i] : 0.0; }
+    }
+    for (int js = 0; js < JT; ++js) {
+      const int ix = js * 64 + lane;
+      const bool valid = row_valid(k, js);
+      const double l = aL[ix], u = aU[ix], v = aV[ix], lam = aW3[ix];
+      const bool lo = valid && l > -INFINITY && lam > 0 && lam > fabs(v - l);
+      const bool up = valid && u < INFINITY && lam < 0 && -lam > fabs(u - v);
+      PA[ix] = (lo || up) ? rho : 0.0; PB[ix] = lo ? l : (up ? u : 0.0); PY[ix] = (lo || up) ? lam : 0.0;
+      PS[ix] = lo ? 1.0 : (up ? -1.0 : 0.0);
+      aD[ix] = PA[ix]; aW1[ix] = 0.0; aW2[ix] = 0.0;
+    }
+    __syncthreads();
+    acc_init<T>(k, acc);
+    pass_syrk<T, NB>(k, acc, P1, P2, P3, MB);
+    __syncthreads();
+    for (int i = lane; i < k.np; i += 64) { R1[i] = 0.0; R2[i] = 0.0; }
+    __syncthreads();
+    bool pok = factor_solve2(-1) == 0;
+    if (!pok) flag_polished = -5;
+    for (int i = lane; i < k.np; i += 64) R2[i] = X[i];   // R2 = polished iterate
+    __syncthreads();
+    for (int pit = 0; pok; ++pit) {
+      {
+        const double* vin[1] = {R2}; double* rout[2] = {aVA, aVC};
+        pass_Av<T, NB, 1, 3>(k, vin, rout, P1, P2);   // v = A~x, y^ = y - rho*act*(v - b), P1 = A~'y^, P2 = A~'(rho*act*(v - b))
+      }
+      for (int jb = 0; jb < k.JB; ++jb) {
+        const int i = jb * 64 + lane, ix = (J + jb) * 64 + lane;
+        const double v = i < n ? R2[i] : 0.0;
+        aVA[ix] = v; aVC[ix] = PY[ix] - PA[ix] * (v - PB[ix]);
+      }
+      hx_full(R2);
+      __syncthreads();
+      double m_rd = 0, m_rp = 0, m_sg = 0, m_cp = 0, fl2 = 0;
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < k.np) {
+          const int ix = (J + (i >> 6)) * 64 + (i & 63);
+          double r = 0.0;
+          if (i < n) {
+            const double gz = P1[i] + aVC[ix];
+            r = HX[i] + G[i] - gz;
+            const double sc = fmax(1.0, fmax(fabs(G[i]), fmax(fabs(HX[i]), fabs(gz))));
+            m_rd = fmax(m_rd, fabs(r) / sc);
+            fl2 += 0.5 * R2[i] * HX[i] + G[i] * R2[i];
+          }
+          DX[i] = -(r + P2[i] + PA[ix] * (aVA[ix] - PB[ix]));   // -grad of the augmented Lagrangian at (x, y^)
+        }
+      }
+      for (int js = 0; js < JT; ++js) {
+        const int ix = js * 64 + lane;
+        if (row_valid(k, js)) {
+          const double l = aL[ix], u = aU[ix], v = aVA[ix], y = aVC[ix], sd = PS[ix];
+          double sc = fmax(1.0, fabs(v));
+          if (l > -INFINITY) sc = fmax(sc, fabs(l));
+          if (u < INFINITY) sc = fmax(sc, fabs(u));
+          double viol = 0.0;
+          if (sd != 0.0) { viol = fabs(v - PB[ix]); m_cp = fmax(m_cp, fabs(y) * viol); }
+          if (l > -INFINITY && v < l) viol = fmax(viol, l - v);
+          if (u < INFINITY && v > u) viol = fmax(viol, v - u);
+          m_rp = fmax(m_rp, viol / sc);
+          m_sg = fmax(m_sg, sd > 0 ? -y : (sd < 0 ? y : 0.0));
+        }
+      }
+      m_rd = wave_max(m_rd); m_rp = wave_max(m_rp); m_sg = wave_max(m_sg); m_cp = wave_max(m_cp);
+      const double f2 = wave_sum(fl2);
+      const bool conv = m_rd <= 1e-10 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2));
+      if (P.dump && b < 32 && P.dump_stage == 3 && lane == 0) { double* o_ = P.dump + 64 * b + 8 * pit; o_[0] = m_rd; o_[1] = m_rp; o_[2] = m_sg; o_[3] = m_cp; o_[4] = conv; o_[5] = f2; }
+      if (conv || pit == 4) {
+        // accept only a true KKT point: multipliers of the right sign (round-off level wrong signs are zeroed)
+        pok = conv && m_sg <= 1e-8;
+        if (!pok) flag_polished = !(m_rd <= 1e-10) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!conv ? -3 : -4));
+        if (pok) {
+          for (int i = lane; i < k.np; i += 64) X[i] = R2[i];
+          for (int js = 0; js < JT; ++js) {
+            const int ix = js * 64 + lane;
+            const double y = aVC[ix], sd = PS[ix];
+            aW3[ix] = sd > 0 ? fmax(y, 0.0) : (sd < 0 ? fmin(y, 0.0) : 0.0);
+          }
+          flag_polished = 1 + pit;
+          fval_s = f2;
+        }
+        __syncthreads();
+        break;
+      }
+      __syncthreads();
+      solve1(DX);
+      __syncthreads();
+      for (int i = lane; i < k.np; i += 64) R2[i] += DX[i];
+      for (int js = 0; js < JT; ++js) PY[js * 64 + lane] = aVC[js * 64 + lane];
+      __syncthreads();
+    }
   }
   const bool have_x = flag == 0 || flag == 1;
   double* xo = P.x + (size_t)b * n;
@@ -1301,9 +1447,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       if (s < k.Kq && r < k.m) lo[n + r] = have_x ? aW3[js * 64 + lane] * Fs[js * 64 + lane] : NAN;
     }
   }
-  if (have_x) {  // objective at the returned point, in the caller's units (H~,g~ scaling is objective preserving)
+  if (have_x && !v_current) {  // objective at the restored point, in the caller's units (H~,g~ scaling is objective preserving)
     __syncthreads();
-    hx_full();
+    hx_full(X);
     __syncthreads();
     double fl = 0;
     for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < n) fl += 0.5 * X[i] * HX[i] + G[i] * X[i]; }
@@ -1315,6 +1461,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     P.fval[b] = have_x ? fval_s : NAN;
     P.exitflag[b] = flag;
     P.iter[b] = it;
+    if (P.polished) P.polished[b] = flag_polished;
   }
 }
 

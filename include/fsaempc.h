@@ -41,7 +41,8 @@ typedef struct {
   double inf_bound;  /* |bound| >= inf_bound is treated as infinite (default 1e9; covers the
                         reference's +-1e10 fillers, kinematic_state_constraints.m:38-39) */
   int    max_iter;   /* interior-point iteration limit (default 100) */
-  int    reserved;
+  int    polish;     /* 1 (default): active-set polish to the vertex-exact point an active-set solver returns;
+                        accepted only if it is a KKT point, otherwise the interior-point iterate is kept */
 } fsaempc_qp_opts;
 
 void fsaempc_qp_default_opts(fsaempc_qp_opts* o);
@@ -162,6 +163,8 @@ int fsaempc_selftest_mfma(void);
 /* Debug hook used by the parity tests: dumps solver internals of instance 0 after `stage`
  * (see qp_solver.hip) into `out` (device pointer, >= 4*nV*nV+8*(nV+nC) doubles). */
 int fsaempc_debug_set_dump(double* out, int stage);
+/* Debug hook: per-instance int array (device, >= batch) that receives 1 where the active-set polish was accepted. */
+int fsaempc_debug_set_polished(int* out);
 
 /* Kernel timing with HIP events recorded on the launch stream of the last fsaempc_qp_solve_batch_device
  * call (prep = scaling/repack kernel, solve = interior-point kernel).  get_timing synchronises on the events. */

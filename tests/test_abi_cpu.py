@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 def test_default_opts_and_dims():
     import fsae_mpc_amd as fm
     o = fm.default_opts()
-    assert o.tol == 1e-8 and o.tol_loose == 1e-6 and o.inf_bound == 1e9 and o.max_iter == 100
+    assert o.tol == 1e-8 and o.tol_loose == 1e-6 and o.inf_bound == 1e9 and o.max_iter == 100 and o.polish == 1
     assert fm.dims(fm.KINEMATIC, 40) == (5, 1, 81, 240) and fm.dims(fm.DYNAMIC, 60) == (7, 4, 124, 1200)
     d = fm._lib.QpDesc(81, 240, 4096, 0)
     assert fm.lib().fsaempc_qp_workspace_bytes(C.byref(d)) > 4096 * 240 * 81 * 8

@@ -170,6 +170,35 @@ def test_solve_parity_generic_mode(fm, torch_, orc, model, N, B):
     assert abs(out["iter"].mean() - ito.mean()) < 3.0   # same algorithm, same iteration profile
 
 
+@pytest.mark.parametrize("model,N,B", [(0, 40, 512), (1, 40, 64), (0, 20, 128)])
+def test_polish_reaches_the_vertex(fm, torch_, orc, model, N, B):
+    """With the active-set polish (default) the HIP path returns the vertex-exact point an active-set solver (qpOASES)
+    stops at: wherever the polish is accepted the result is a KKT point to 1e-9 (relative) and x agrees with the oracle's LU-polished solution to round-off (the few larger x gaps are instances
+    where the oracle's own polish was rejected and the oracle returned its interior-point iterate); with the polish
+    switched off the interior-point iterate is returned (same KKT tolerance, looser x)."""
+    torch = torch_
+    otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, otr.L, 20190, range(B))
+    q = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul)
+    xo, fo, flo, ito, lamo, _ = orc.qp_solve_batch(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"])
+    pol = torch.zeros(B, dtype=torch.int32, device="cuda")
+    fm.lib().fsaempc_debug_set_polished(C.c_void_p(pol.data_ptr()))
+    try:
+        out = _solve_dev(fm, torch, q)
+    finally:
+        fm.lib().fsaempc_debug_set_polished(None)
+    pol = pol.cpu().numpy() > 0
+    assert (out["exitflag"] == 0).all() and pol.mean() >= 0.6, pol.mean()
+    ex = np.abs(out["x"] - xo).max(axis=1) / np.maximum(1, np.abs(xo).max(axis=1))
+    assert np.median(ex[pol]) <= 1e-9 and np.percentile(ex[pol], 90) <= 1e-7, (np.median(ex[pol]), np.percentile(ex[pol], 90))
+    assert (np.abs(out["fval"] - fo) <= FVAL_TOL * np.maximum(1, np.abs(fo))).all()
+    kkt = np.array([orc.qp_kkt(q["H"][b].T, q["g"][b], q["A"][b].T, q["lb"][b], q["ub"][b], q["lbA"][b], q["ubA"][b], out["x"][b], out["lam"][b])[0]
+                    for b in range(B)])
+    assert kkt.max() <= KKT_TOL and kkt[pol].max() <= 1e-9
+    off = _solve_dev(fm, torch, q, options=fm.default_opts(polish=0))
+    assert (off["exitflag"] == 0).all() and np.abs(off["fval"] - out["fval"]).max() <= FVAL_TOL * np.abs(fo).max()
+
+
 def test_fused_step_parity(fm, torch_, orc):
     torch = torch_
     otr = orc.Track.load(fm.tracks._HERE + "/tracks/fss2019.json")
