@@ -7,11 +7,12 @@ struct QpDims {
   int n, m;        // variables, general rows
   int T, np;       // 16-wide column tiles of the MFMA core (nc = 16T columns), padded vector length
   int nb, NB, nc;  // border columns (n mod 16 in 1..4 are kept off the matrix cores), template border width (0,1,4), core columns
-  int Kq;          // MFMA k-steps = rows per lane group = ceil(m/4)
+  int Kq, ntr;     // MFMA k-steps = rows per lane group = ceil(m/4); trips of 4 k-steps
+  int prep_tw;     // columns staged per pass of the prep kernel's A transpose
   int J, JB;       // owner-layout slots for rows / for variable bounds
   int ld;          // leading dimension of the LDS normal matrix
   int rowlen;      // (J+JB)*64
-  size_t off_Aw, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, ws_per_qp;  // in doubles
+  size_t off_Aw, off_meta, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, ws_per_qp;  // in doubles
   size_t lds_solve, lds_prep;                                                  // in bytes
 };
 

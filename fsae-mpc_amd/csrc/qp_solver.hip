@@ -9,11 +9,17 @@
 // accumulators resident in registers, plus three light streaming passes over A.
 //
 // Data layout (all per QP, in the device workspace, written once by qp_prep_kernel):
-//   Aw [Kq/2][T][64][2] scaled A in MFMA-operand stream order, two k-steps per 16-byte lane load: k-step s, column tile t, lane (c=l&15,q=l>>4)
-//                    holds A~[r = q*Kq + s][16t + c]   (the K order of the MFMA is permuted so that each
-//                    lane group walks a contiguous row range; every load is one coalesced 512 B line set)
+//   rows             are permuted once (qp_prep_kernel): sorted by the last column tile that holds a nonzero, then dealt
+//                    round-robin to the four lane groups: sorted position p <-> k-step s = p>>2, lane group q = p&3.
+//                    A *trip* = 4 k-steps = 16 sorted rows; tcs[trip] = number of leading column tiles that hold a
+//                    nonzero in any of them.  The condensed LTV-MPC constraints are block lower-triangular (row k only
+//                    sees the inputs up to step k), so on average ~60 % of the tiles and ~47 % of the MFMAs remain; a
+//                    dense A keeps tcs = T everywhere and costs nothing extra.
+//   Aw               scaled A in MFMA-operand stream order: trip, pair of k-steps u, tile t < tcs[trip], lane, 2 k-steps
+//                    (16-byte lane loads); lane (c=l&15,q=l>>4) of k-step s holds A~[perm[4s+q]][16t + c].
+//                    aoff[trip] = start of the trip in records of 128 doubles; tend[C] = number of trips with tcs <= C.
 //   Hw [T*T][4][64]  scaled H in accumulator (C/D) layout: tile (I,J), reg p, lane -> H~[16I+q+4p][16J+c]
-//   row vectors      "owner layout" [slot][64]: slot js<J, lane (c,q) <-> row r = q*Kq + 16js + c;
+//   row vectors      "owner layout" [slot][64]: slot js<J, lane (c,q) <-> k-step s = 16js + c, sorted position 4s + q;
 //                    slots J..J+JB-1 hold the variable-bound rows i = (js-J)*64 + lane.
 // fp64 MFMA lane maps (cdna_hip_programming.md section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 // C/D col = l&15, row = (l>>4) + 4*reg.  fsaempc_selftest_mfma() checks them on the device.
@@ -99,12 +105,23 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   double* Fs = ws + d.off_F;   // owner layout, J slots
   double* Ab = ws + d.off_Ab;  // 4 border columns of A~, owner layout
   double* Hb = ws + d.off_Hb;  // 4 border columns of H~ (full length np)
+  int* perm_g = reinterpret_cast<int*>(ws + d.off_meta);          // owner layout: original row of each sorted position (-1: padding)
+  int* tcs_g = perm_g + (size_t)(J > 0 ? J : 1) * 64;              // [ntr] tiles per trip
+  int* aoff_g = tcs_g + d.ntr;                                     // [ntr+1] start of each trip in the operand stream
+  int* tend_g = aoff_g + d.ntr + 1;                                // [T+1] trips with tcs <= C
+  const int ntr = d.ntr;
   double* Lr = ws + d.off_rows + 0 * (size_t)d.rowlen;  // scaled lower bounds (owner layout, rows then vars)
   double* Ur = ws + d.off_rows + 1 * (size_t)d.rowlen;
   extern __shared__ double lds[];
   double* Esh = lds;            // np
   double* red = lds + np;       // 4 partial maxima
   double* tile = red + 4;       // 16 x (4Kq+1) staging for the A transpose
+  const int TW = d.prep_tw;     // columns staged per pass (16, or fewer when 16 x 4Kq doubles would not fit the LDS)
+  int* cls_sh = reinterpret_cast<int*>(tile + TW * (4 * Kq + 1));   // [4Kq] tile class of every original row
+  int* perm_sh = cls_sh + 4 * Kq;                                    // [16 ntr] original row of every sorted position
+  int* cnt_sh = perm_sh + 16 * ntr;                                  // [T+1] class counts / starts ; then tcs [ntr], aoff [ntr+1]
+  int* tcs_sh = cnt_sh + 16;
+  int* aoff_sh = tcs_sh + ntr;
 
   // ---- column scaling E_j = 1/sqrt(H_jj), or 1/max|A_:j| where H_jj ~ 0 (slack columns) ----
   for (int j = tid; j < np; j += 256) {
@@ -130,15 +147,55 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   }
   for (int j = tid; j < np; j += 256) { Es[j] = Esh[j]; gw[j] = j < n ? g[j] * Esh[j] : 0.0; }
 
+  // ---- row order: class = last core column tile with a nonzero; stable counting sort by class ----
+  if (tid < 16) cnt_sh[tid] = 0;
+  __syncthreads();
+  const int ncols = nc < n ? nc : n;
+  for (int r = tid; r < m; r += 256) {
+    int e = 0;
+    for (int col = ncols - 1; col >= 0; --col)
+      if (A[(size_t)col * m + r] != 0.0) { e = col >> 4; break; }
+    cls_sh[r] = e;
+    atomicAdd(&cnt_sh[e], 1);
+  }
+  __syncthreads();
+  if (tid == 0) { int run = 0; for (int e = 0; e < T; ++e) { const int cn = cnt_sh[e]; cnt_sh[e] = run; run += cn; } }
+  for (int p = tid; p < 16 * ntr; p += 256) perm_sh[p] = -1;
+  __syncthreads();
+  for (int r = tid; r < m; r += 256) {
+    const int e = cls_sh[r];
+    int rank = 0;
+    for (int r2 = 0; r2 < r; ++r2) rank += (cls_sh[r2] == e);
+    perm_sh[cnt_sh[e] + rank] = r;
+  }
+  __syncthreads();
+  // tiles per trip (16 sorted positions), stream offsets, phase ends
+  for (int tr = tid; tr < ntr; tr += 256) {
+    int tc = 1;
+    for (int p = 16 * tr; p < 16 * tr + 16; ++p) { const int r = perm_sh[p]; if (r >= 0) tc = max(tc, cls_sh[r] + 1); }
+    tcs_sh[tr] = tc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int tr = 0; tr < ntr; ++tr) { aoff_sh[tr] = run; run += 2 * tcs_sh[tr]; }
+    aoff_sh[ntr] = run;
+    for (int C = 0; C <= T; ++C) { int cn = 0; for (int tr = 0; tr < ntr; ++tr) cn += (tcs_sh[tr] <= C); tend_g[C] = cn; }
+  }
+  __syncthreads();
+  for (int tr = tid; tr <= ntr; tr += 256) { aoff_g[tr] = aoff_sh[tr]; if (tr < ntr) tcs_g[tr] = tcs_sh[tr]; }
+
   // ---- row scaling F_r = 1/max_j |A[r][j] E_j| ; rows handled in owner layout, one slot per wavefront and trip ----
   for (int js = w; js < J; js += 4) {
-    const int s = 16 * js + c, r = q * Kq + s;
-    const bool valid = s < Kq && r < m;
+    const int s = 16 * js + c, pp = 4 * s + q;
+    const int r = (s < 4 * ntr) ? perm_sh[pp] : -1;
+    const bool valid = r >= 0;
     double rm = 0;
     if (valid)
       for (int j = 0; j < n; ++j) rm = fmax(rm, fabs(A[(size_t)j * m + r]) * Esh[j]);
     double f = (valid && rm > 1e-12) ? 1.0 / rm : (valid ? 1.0 : 0.0);
     Fs[js * 64 + lane] = f;
+    perm_g[js * 64 + lane] = r;
     for (int bb = 0; bb < 4; ++bb)
       Ab[(size_t)bb * J * 64 + js * 64 + lane] = (valid && bb < nb) ? A[(size_t)(nc + bb) * m + r] * Esh[nc + bb] * f : 0.0;
     double l = -INFINITY, u = INFINITY;
@@ -165,22 +222,26 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
 
   // ---- A -> operand stream.  Column tile by column tile: coalesced column reads -> LDS -> lane order ----
   const int R4 = 4 * Kq, mp1 = R4 + 1;  // padded LDS row length (odd => conflict-free across the 16 columns)
-  for (int t = 0; t < T; ++t) {
-    for (int e = tid; e < 16 * R4; e += 256) {
-      const int cc = e / R4, r = e - cc * R4;   // r = position in the permuted K order = row index (lane groups own contiguous rows)
-      const int col = 16 * t + cc;
-      double v = 0.0;
-      if (col < nc && col < n && r < m) v = A[(size_t)col * m + r] * Esh[col];
-      tile[cc * mp1 + r] = v;
+  for (int t = 0; t < T; ++t)
+    for (int c0 = 0; c0 < 16; c0 += TW) {
+      for (int e = tid; e < TW * R4; e += 256) {
+        const int cc = e / R4, r = e - cc * R4;
+        const int col = 16 * t + c0 + cc;
+        double v = 0.0;
+        if (col < nc && col < n && r < m) v = A[(size_t)col * m + r] * Esh[col];
+        tile[cc * mp1 + r] = v;
+      }
+      __syncthreads();
+      for (int s = w; s < 4 * ntr; s += 4) {   // k-steps are stored in pairs (16 B per lane and load); padded positions carry zeros
+        const int tr = s >> 2, tc = tcs_sh[tr];
+        if (t < tc && c >= c0 && c < c0 + TW) {
+          const int r = perm_sh[4 * s + q];
+          const double v = r >= 0 ? tile[(c - c0) * mp1 + r] * Fs[(s >> 4) * 64 + q * 16 + (s & 15)] : 0.0;
+          Aw[((size_t)aoff_sh[tr] + ((s >> 1) & 1) * tc + t) * 128 + lane * 2 + (s & 1)] = v;
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    for (int s = w; s < 2 * ((Kq + 1) / 2); s += 4) {   // k-steps are stored in pairs (16 B per lane and load); odd tail zero-filled
-      double v = 0.0;
-      if (s < Kq) { const int r = q * Kq + s; v = tile[c * mp1 + r] * Fs[(s >> 4) * 64 + q * 16 + (s & 15)]; }
-      Aw[((size_t)(s >> 1) * T + t) * 128 + lane * 2 + (s & 1)] = v;
-    }
-    __syncthreads();
-  }
 
   // ---- H -> accumulator-layout tiles (T x T grid of the core; symmetric read for coalescing) ----
   for (int idx = w; idx < T * T * 4; idx += 4) {
@@ -200,7 +261,8 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
 // solve kernel
 // ---------------------------------------------------------------------------------------------
 struct Ctx {
-  int n, m, T, Kq, J, JB, JT, np, ld, lane, c, q, nc, nb;
+  int n, m, T, Kq, J, JB, JT, np, ld, lane, c, q, nc, nb, ntr;
+  const int* perm; const int* tcs; const int* aoff; const int* tend;   // row order and operand-stream directory (qp_prep_kernel)
   const double* Aw; const double* Hw; const double* Ab; const double* Hb;
   double* rows;  // base of owner-layout row arrays
   int rowlen;
@@ -214,7 +276,7 @@ DEVINL double* rowp(const Ctx& k, int arr) { return k.rows + (size_t)arr * k.row
 DEVINL double* vecp(const Ctx& k, int arr) { return k.vec + arr * k.np; }
 
 DEVINL bool row_valid(const Ctx& k, int js) {
-  if (js < k.J) { const int s = 16 * js + k.c; return s < k.Kq && (k.q * k.Kq + s) < k.m; }
+  if (js < k.J) { const int s = 16 * js + k.c; return s < k.Kq && 4 * s + k.q < k.m; }
   return (js - k.J) * 64 + k.lane < k.n;
 }
 
@@ -268,17 +330,20 @@ template <int T> DEVINL void acc_init(const Ctx& k, v4d* acc) {
     }
 }
 
+template <int C> struct IC { static constexpr int value = C; };
+
 // pass 1: acc += A~' D A~ on the matrix cores; p1 = A~'w1, p2 = A~'w2, p3 = A~'w3 on the VALU beside them.
-// A ring of PF k-steps of operands is kept in flight (L2 / Infinity-Cache latency under load is ~2-3k cycles,
-// one k-step of MFMA work is ~1.3k cycles).
+// The stream is walked trip by trip (4 k-steps); a trip with tc column tiles only touches the tc(tc+1)/2 accumulator
+// tiles it can reach.  Trips are sorted by tc, so the pass is T phases with compile-time tile counts (phase C: all
+// trips with tc == C) and no branches inside a trip.  The operands of the next trip are in flight while one is
+// consumed (two pairs of k-steps = 2 x tc x 1 KB per wave).
 template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, double* P2, double* P3, double* MB) {
-  constexpr int PF = 2;   // pairs of k-steps in flight
   constexpr int NBB = NB > 0 ? NB : 1;
   const double* D = rowp(k, R_D); const double* W1 = rowp(k, R_W1);
   const double* W2 = rowp(k, R_W2); const double* W3 = rowp(k, R_W3);
-  const int JS = k.J * 64, Kq2 = (k.Kq + 1) >> 1;
-  double p1[T], p2[T], p3[T], cq[PF][2][4 + NBB];
-  v2d bq[PF][T];
+  const int JS = k.J * 64, ntr = k.ntr;
+  double p1[T], p2[T], p3[T], cq[2][2][4 + NBB];
+  v2d bq[2][T];
   double pb[NBB][T], sbb[NBB][NBB], pwb[3][NBB];   // border: column of A'DA, border block, border entries of p1..p3
 #pragma unroll
   for (int t = 0; t < T; ++t) { p1[t] = 0; p2[t] = 0; p3[t] = 0; }
@@ -290,69 +355,62 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
     for (int f = 0; f < NBB; ++f) sbb[e][f] = 0;
     pwb[0][e] = pwb[1][e] = pwb[2][e] = 0;
   }
-  auto issue = [&](int u, int s2) {
+  // loads of pair u of trip tr (tc tiles; wave-uniform guards, the tiles beyond tc are never read by that trip's phase)
+  auto issue = [&](int u, int tr) {
+    const int tc = k.tcs[tr];
+    const double* src = k.Aw + ((size_t)k.aoff[tr] + u * tc) * 128 + k.lane * 2;
 #pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = *reinterpret_cast<const v2d*>(k.Aw + ((size_t)s2 * T + t) * 128 + k.lane * 2);
+    for (int t = 0; t < T; ++t)
+      if (t < tc) bq[u][t] = *reinterpret_cast<const v2d*>(src + t * 128);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int s = 2 * s2 + h;
-      if (s < k.Kq) {
-        const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-        cq[u][h][0] = D[ri]; cq[u][h][1] = W1[ri]; cq[u][h][2] = W2[ri]; cq[u][h][3] = W3[ri];
+      const int s = 4 * tr + 2 * u + h;
+      const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+      cq[u][h][0] = D[ri]; cq[u][h][1] = W1[ri]; cq[u][h][2] = W2[ri]; cq[u][h][3] = W3[ri];
 #pragma unroll
-        for (int e = 0; e < NB; ++e) cq[u][h][4 + e] = k.Ab[(size_t)e * JS + ri];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4 + NBB; ++e) cq[u][h][e] = 0.0;
-      }
+      for (int e = 0; e < NB; ++e) cq[u][h][4 + e] = k.Ab[(size_t)e * JS + ri];
     }
   };
+  if (ntr > 0) { issue(0, 0); issue(1, 0); }
+  int tr = 0;
+  auto phase = [&](auto Cc) {
+    constexpr int C = decltype(Cc)::value;
+    const int tr_end = k.tend[C];
+    for (; tr < tr_end; ++tr) {
+      const int trn = min(tr + 1, ntr - 1);
 #pragma unroll
-  for (int u = 0; u < PF; ++u) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = v2d{0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int e = 0; e < 4 + NBB; ++e) cq[u][h][e] = 0.0;
-    if (u < Kq2) issue(u, u);
-  }
-  for (int s0 = 0; s0 < Kq2; s0 += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int s2 = s0 + u;
-      if (s2 < Kq2) {
-        double bc[2][T], cf[2][4 + NBB];
+      for (int u = 0; u < 2; ++u) {
+        double bc[2][C], cf[2][4 + NBB];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int t = 0; t < T; ++t) bc[h][t] = bq[u][t][h];
+          for (int t = 0; t < C; ++t) bc[h][t] = bq[u][t][h];
 #pragma unroll
           for (int e = 0; e < 4 + NBB; ++e) cf[h][e] = cq[u][h][e];
         }
-        if (s2 + PF < Kq2) issue(u, s2 + PF);
+        issue(u, trn);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          double a[T], ab[NBB];
+          double a[C], ab[NBB];
           const double dd = cf[h][0], w1 = cf[h][1], w2 = cf[h][2], w3 = cf[h][3];
 #pragma unroll
           for (int e = 0; e < NB; ++e) ab[e] = cf[h][4 + e];
 #pragma unroll
-          for (int t = 0; t < T; ++t) a[t] = dd * bc[h][t];
+          for (int t = 0; t < C; ++t) a[t] = dd * bc[h][t];
 #pragma unroll
-          for (int I = 0; I < T; ++I)
+          for (int I = 0; I < C; ++I)
 #pragma unroll
-            for (int Jt = I; Jt < T; ++Jt)
+            for (int Jt = I; Jt < C; ++Jt)
               acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], bc[h][Jt], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
+          for (int t = 0; t < C; ++t) {
             p1[t] = fma(w1, bc[h][t], p1[t]); p2[t] = fma(w2, bc[h][t], p2[t]); p3[t] = fma(w3, bc[h][t], p3[t]);
           }
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
             const double dab = dd * ab[e];
 #pragma unroll
-            for (int t = 0; t < T; ++t) pb[e][t] = fma(dab, bc[h][t], pb[e][t]);
+            for (int t = 0; t < C; ++t) pb[e][t] = fma(dab, bc[h][t], pb[e][t]);
 #pragma unroll
             for (int f = e; f < NB; ++f) sbb[e][f] = fma(dab, ab[f], sbb[e][f]);
             pwb[0][e] = fma(w1, ab[e], pwb[0][e]); pwb[1][e] = fma(w2, ab[e], pwb[1][e]); pwb[2][e] = fma(w3, ab[e], pwb[2][e]);
@@ -360,7 +418,15 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
         }
       }
     }
-  }
+  };
+  if constexpr (T >= 1) phase(IC<1>{});
+  if constexpr (T >= 2) phase(IC<2>{});
+  if constexpr (T >= 3) phase(IC<3>{});
+  if constexpr (T >= 4) phase(IC<4>{});
+  if constexpr (T >= 5) phase(IC<5>{});
+  if constexpr (T >= 6) phase(IC<6>{});
+  if constexpr (T >= 7) phase(IC<7>{});
+  if constexpr (T >= 8) phase(IC<8>{});
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     double v1 = q_sum(p1[t]), v2 = q_sum(p2[t]), v3 = q_sum(p3[t]);
@@ -386,11 +452,10 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
 template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor, double* Pcor2 = nullptr) {
-  constexpr int PF = 2;   // pairs of k-steps in flight (little compute per step => latency bound otherwise)
   constexpr int NBB = NB > 0 ? NB : 1;
-  const int JS = k.J * 64, Kq2 = (k.Kq + 1) >> 1;
-  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], pd[FUSE >= 2 ? T : 1], pdb[NBB], cq[PF][2][6 + NBB];
-  v2d bq[PF][T];
+  const int JS = k.J * 64, ntr = k.ntr;
+  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], pd[FUSE >= 2 ? T : 1], pdb[NBB], cq[2][2][6 + NBB];
+  v2d bq[2][T];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e) {
 #pragma unroll
@@ -406,91 +471,92 @@ template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, c
   for (int t = 0; t < (FUSE >= 2 ? T : 1); ++t) pd[t] = 0.0;
   const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
   const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
-  auto issue = [&](int u, int s2) {
+  auto issue = [&](int u, int tr) {   // same ring as pass 1: the next trip is in flight while one is consumed
+    const int tc = k.tcs[tr];
+    const double* src = k.Aw + ((size_t)k.aoff[tr] + u * tc) * 128 + k.lane * 2;
 #pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = *reinterpret_cast<const v2d*>(k.Aw + ((size_t)s2 * T + t) * 128 + k.lane * 2);
+    for (int t = 0; t < T; ++t)
+      if (t < tc) bq[u][t] = *reinterpret_cast<const v2d*>(src + t * 128);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int s = 2 * s2 + h;
-      if (s < k.Kq) {
-        const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-        if (FUSE == 1) { cq[u][h][0] = CA1[ri]; cq[u][h][1] = CB1[ri]; cq[u][h][2] = CC1[ri]; cq[u][h][3] = CA2[ri]; cq[u][h][4] = CB2[ri]; cq[u][h][5] = CC2[ri]; }
-        if (FUSE >= 2) { cq[u][h][0] = CB1[ri]; cq[u][h][1] = CA1[ri]; cq[u][h][2] = CC1[ri]; }   // polish: rho*act, target b, multiplier y
+      const int s = 4 * tr + 2 * u + h;
+      const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
+      if (FUSE == 1) { cq[u][h][0] = CA1[ri]; cq[u][h][1] = CB1[ri]; cq[u][h][2] = CC1[ri]; cq[u][h][3] = CA2[ri]; cq[u][h][4] = CB2[ri]; cq[u][h][5] = CC2[ri]; }
+      if (FUSE >= 2) { cq[u][h][0] = CB1[ri]; cq[u][h][1] = CA1[ri]; cq[u][h][2] = CC1[ri]; }   // polish: rho*act, target b, multiplier y
 #pragma unroll
-        for (int f = 0; f < NB; ++f) cq[u][h][6 + f] = k.Ab[(size_t)f * JS + ri];
-      }
+      for (int f = 0; f < NB; ++f) cq[u][h][6 + f] = k.Ab[(size_t)f * JS + ri];
     }
   };
-#pragma unroll
-  for (int u = 0; u < PF; ++u) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) bq[u][t] = v2d{0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int e = 0; e < 6 + NBB; ++e) cq[u][h][e] = 0.0;
-    if (u < Kq2) issue(u, u);
-  }
+  if (ntr > 0) { issue(0, 0); issue(1, 0); }
   double keep[NVEC + 1];   // last entry: the updated multiplier of the polish modes (written to rout[NVEC])
 #pragma unroll
   for (int e = 0; e < NVEC + 1; ++e) keep[e] = 0.0;
-  for (int s0 = 0; s0 < Kq2; s0 += PF) {
+  int tr = 0;
+  auto phase = [&](auto Cc) {
+    constexpr int C = decltype(Cc)::value;
+    const int tr_end = k.tend[C];
+    for (; tr < tr_end; ++tr) {
+      const int trn = min(tr + 1, ntr - 1);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int s2 = s0 + u;
-      if (s2 < Kq2) {
-        double bc[2][T], cf[2][6 + NBB];
+      for (int u = 0; u < 2; ++u) {
+        double bc[2][C], cf[2][6 + NBB];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int t = 0; t < T; ++t) bc[h][t] = bq[u][t][h];
+          for (int t = 0; t < C; ++t) bc[h][t] = bq[u][t][h];
 #pragma unroll
           for (int e = 0; e < 6 + NBB; ++e) cf[h][e] = cq[u][h][e];
         }
-        if (s2 + PF < Kq2) issue(u, s2 + PF);
+        issue(u, trn);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int s = 2 * s2 + h;
-          if (s < k.Kq) {
-            const int cc = s & 15;
+          const int s = 4 * tr + 2 * u + h;
+          const int cc = s & 15;
 #pragma unroll
-            for (int e = 0; e < NVEC; ++e) {
-              double dsum = 0.0;
+          for (int e = 0; e < NVEC; ++e) {
+            double dsum = 0.0;
 #pragma unroll
-              for (int t = 0; t < T; ++t) dsum = fma(bc[h][t], v[e][t], dsum);
-              dsum = grp16_sum(dsum);
+            for (int t = 0; t < C; ++t) dsum = fma(bc[h][t], v[e][t], dsum);
+            dsum = grp16_sum(dsum);
 #pragma unroll
-              for (int f = 0; f < NB; ++f) dsum = fma(cf[h][6 + f], vb[e][f], dsum);
-              if (k.c == cc) keep[e] = dsum;
-              if (FUSE >= 2 && e == 0) {   // polish: pen = rho*act*(v - b), y^ = y - pen; accumulate A~'y^ and A~'pen
-                const double pen = cf[h][0] * (dsum - cf[h][1]);
-                const double ynew = cf[h][2] - pen;
-                if (k.c == cc) keep[NVEC] = ynew;
+            for (int f = 0; f < NB; ++f) dsum = fma(cf[h][6 + f], vb[e][f], dsum);
+            if (k.c == cc) keep[e] = dsum;
+            if (FUSE >= 2 && e == 0) {   // polish: pen = rho*act*(v - b), y^ = y - pen; accumulate A~'y^ and A~'pen
+              const double pen = cf[h][0] * (dsum - cf[h][1]);
+              const double ynew = cf[h][2] - pen;
+              if (k.c == cc) keep[NVEC] = ynew;
 #pragma unroll
-                for (int t = 0; t < T; ++t) { pc[t] = fma(ynew, bc[h][t], pc[t]); pd[t] = fma(pen, bc[h][t], pd[t]); }
+              for (int t = 0; t < C; ++t) { pc[t] = fma(ynew, bc[h][t], pc[t]); pd[t] = fma(pen, bc[h][t], pd[t]); }
 #pragma unroll
-                for (int f = 0; f < NB; ++f) { pcb[f] = fma(ynew, cf[h][6 + f], pcb[f]); pdb[f] = fma(pen, cf[h][6 + f], pdb[f]); }
-              }
-              if (FUSE == 1 && e == 0) {
-                const double dl_ = dsum + cf[h][0], du_ = cf[h][3] - dsum;
-                const double w = dl_ * fma(cf[h][2], dl_, cf[h][1]) - du_ * fma(cf[h][5], du_, cf[h][4]);
-#pragma unroll
-                for (int t = 0; t < T; ++t) pc[t] = fma(w, bc[h][t], pc[t]);
-#pragma unroll
-                for (int f = 0; f < NB; ++f) pcb[f] = fma(w, cf[h][6 + f], pcb[f]);
-              }
+              for (int f = 0; f < NB; ++f) { pcb[f] = fma(ynew, cf[h][6 + f], pcb[f]); pdb[f] = fma(pen, cf[h][6 + f], pdb[f]); }
             }
-            if (cc == 15 || s + 1 == k.Kq) {
-              const int js = s >> 4;
+            if (FUSE == 1 && e == 0) {
+              const double dl_ = dsum + cf[h][0], du_ = cf[h][3] - dsum;
+              const double w = dl_ * fma(cf[h][2], dl_, cf[h][1]) - du_ * fma(cf[h][5], du_, cf[h][4]);
 #pragma unroll
-              for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
-              if (FUSE >= 2) { rout[NVEC][js * 64 + k.lane] = keep[NVEC]; keep[NVEC] = 0.0; }
+              for (int t = 0; t < C; ++t) pc[t] = fma(w, bc[h][t], pc[t]);
+#pragma unroll
+              for (int f = 0; f < NB; ++f) pcb[f] = fma(w, cf[h][6 + f], pcb[f]);
             }
+          }
+          if (cc == 15 || s + 1 == 4 * ntr) {
+            const int js = s >> 4;
+#pragma unroll
+            for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
+            if (FUSE >= 2) { rout[NVEC][js * 64 + k.lane] = keep[NVEC]; keep[NVEC] = 0.0; }
           }
         }
       }
     }
-  }
+  };
+  if constexpr (T >= 1) phase(IC<1>{});
+  if constexpr (T >= 2) phase(IC<2>{});
+  if constexpr (T >= 3) phase(IC<3>{});
+  if constexpr (T >= 4) phase(IC<4>{});
+  if constexpr (T >= 5) phase(IC<5>{});
+  if constexpr (T >= 6) phase(IC<6>{});
+  if constexpr (T >= 7) phase(IC<7>{});
+  if constexpr (T >= 8) phase(IC<8>{});
   if (FUSE) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -520,11 +586,14 @@ template <int T, int NB> DEVINL void pass_Atw(const Ctx& k, const double* W, dou
   for (int t = 0; t < T; ++t) p[t] = 0.0;
 #pragma unroll
   for (int f = 0; f < NBB; ++f) pbv[f] = 0.0;
-  for (int s = 0; s < k.Kq; ++s) {
+  for (int s = 0; s < 4 * k.ntr; ++s) {
     const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
     const double w = W[ri];
+    const int tr = s >> 2, tc = k.tcs[tr];
+    const double* src = k.Aw + ((size_t)k.aoff[tr] + ((s >> 1) & 1) * tc) * 128 + k.lane * 2 + (s & 1);
 #pragma unroll
-    for (int t = 0; t < T; ++t) p[t] = fma(w, k.Aw[((size_t)(s >> 1) * T + t) * 128 + k.lane * 2 + (s & 1)], p[t]);
+    for (int t = 0; t < T; ++t)
+      if (t < tc) p[t] = fma(w, src[t * 128], p[t]);
 #pragma unroll
     for (int f = 0; f < NB; ++f) pbv[f] = fma(w, k.Ab[(size_t)f * JS + ri], pbv[f]);
   }
@@ -589,28 +658,48 @@ DEVINL v4d tile_load_t(const Ctx& k, const double* slot) {
   return Z;
 }
 
-// Factorise one 16x16 diagonal tile D = U'U in place by 16 row steps (4 panels x 4 rows; the rows of later panels
-// are updated by one K=4 MFMA per panel) and apply the same row operations to two companion tiles: Yk (enters as
-// the identity, leaves as U^-T) and the right-hand-side tile rk (leaves as U^-T rk).  Only these three tiles see
-// VALU work; every other tile of the factorisation is touched by the matrix cores alone.
+// Factorise one 16x16 diagonal tile D = U'U in place, four 4-row panels, and apply the same row operations to two
+// companion tiles: Yk (enters as the identity, leaves as U^-T) and the right-hand-side tile rk (leaves as U^-T rk).
+// Per panel p: the 4x4 diagonal block (10 numbers, read with v_readlane) is factorised and inverted redundantly by
+// every lane -- W = R^-T, wave-uniform -- and applied to the panel rows of the three tiles as one K=4 MFMA each
+// (A operand = W scattered to the panel's rows); the rows of the later panels are then updated by one more K=4 MFMA
+// per tile.  No cross-lane data movement besides the readlanes, no LDS.  (The former version walked the 16 rows one
+// by one with three ds_bpermute round trips per row: 12k cycles per tile, 80 % of the whole factorisation.)
+// Only these three tiles see VALU work; every other tile of the factorisation is touched by the matrix cores alone.
 DEVINL int diag_factor(const Ctx& k, v4d& Ud, v4d& Yk, v4d& rk, double floor_abs) {
   int bad = 0;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-#pragma unroll 1
-    for (int qq = 0; qq < 4; ++qq) {
-      const int kk = 4 * p + qq;
-      double d = rl(Ud[p], 16 * qq + kk);
-      if (!(d > floor_abs)) { if (!(fabs(d) < INFINITY)) bad = 1; d = floor_abs; }
-      const double rinv = rsqrt(d);
-      const double f = (k.q == qq) ? rinv : 1.0;
-      Ud[p] *= f; Yk[p] *= f; rk[p] *= f;
-      double coef = 0.0;
-      for (int q2 = qq + 1; q2 < 4; ++q2) { const double sc = rl(Ud[p], 16 * qq + 4 * p + q2); coef = (k.q == q2) ? sc : coef; }
-      const int src = k.c + 16 * qq;
-      const double u = __shfl(Ud[p], src), y = __shfl(Yk[p], src), r = __shfl(rk[p], src);
-      Ud[p] = fma(-coef, u, Ud[p]); Yk[p] = fma(-coef, y, Yk[p]); rk[p] = fma(-coef, r, rk[p]);
-    }
+    // D[a][b] = M[4p+a][4p+b] lives in lane (c = 4p+b, q = a), register p
+    const double d00 = rl(Ud[p], 4 * p + 0), d01 = rl(Ud[p], 4 * p + 1), d02 = rl(Ud[p], 4 * p + 2), d03 = rl(Ud[p], 4 * p + 3);
+    const double d11 = rl(Ud[p], 16 + 4 * p + 1), d12 = rl(Ud[p], 16 + 4 * p + 2), d13 = rl(Ud[p], 16 + 4 * p + 3);
+    const double d22 = rl(Ud[p], 32 + 4 * p + 2), d23 = rl(Ud[p], 32 + 4 * p + 3);
+    const double d33 = rl(Ud[p], 48 + 4 * p + 3);
+    auto piv = [&](double t) { if (!(t > floor_abs)) { if (!(fabs(t) < INFINITY)) bad = 1; t = floor_abs; } return rsqrt(t); };
+    // R'R = D (R upper triangular), i_a = 1/R[a][a]
+    const double i0 = piv(d00);
+    const double r01 = d01 * i0, r02 = d02 * i0, r03 = d03 * i0;
+    const double i1 = piv(fma(-r01, r01, d11));
+    const double r12 = fma(-r01, r02, d12) * i1, r13 = fma(-r01, r03, d13) * i1;
+    const double i2 = piv(fma(-r12, r12, fma(-r02, r02, d22)));
+    const double r23 = fma(-r12, r13, fma(-r02, r03, d23)) * i2;
+    const double i3 = piv(fma(-r23, r23, fma(-r13, r13, fma(-r03, r03, d33))));
+    // W = (R')^-1, lower triangular
+    const double w10 = -r01 * i0 * i1;
+    const double w20 = -fma(r12, w10, r02 * i0) * i2, w21 = -r12 * i1 * i2;
+    const double w30 = -fma(r23, w20, fma(r13, w10, r03 * i0)) * i3, w31 = -fma(r23, w21, r13 * i1) * i3, w32 = -r23 * i2 * i3;
+    // A operand: lane (i = c, kq = q) holds W[c-4p][q] on the panel's rows, 0 elsewhere
+    const int a_ = k.c - 4 * p;
+    double wa = 0.0;
+    if (k.q == 0) wa = a_ == 0 ? i0 : (a_ == 1 ? w10 : (a_ == 2 ? w20 : (a_ == 3 ? w30 : 0.0)));
+    if (k.q == 1) wa = a_ == 1 ? i1 : (a_ == 2 ? w21 : (a_ == 3 ? w31 : 0.0));
+    if (k.q == 2) wa = a_ == 2 ? i2 : (a_ == 3 ? w32 : 0.0);
+    if (k.q == 3) wa = a_ == 3 ? i3 : 0.0;
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    const v4d nu = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, Ud[p], z, 0, 0, 0);
+    const v4d ny = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, Yk[p], z, 0, 0, 0);
+    const v4d nr = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, rk[p], z, 0, 0, 0);
+    Ud[p] = nu[p]; Yk[p] = ny[p]; rk[p] = nr[p];
     if (p < 3) {
       const double a = (k.c > 4 * p + 3) ? -Ud[p] : 0.0;
       Yk = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Yk[p], Yk, 0, 0, 0);
@@ -724,7 +813,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
   double* ws = P.ws + (size_t)b * d.ws_per_qp;
   k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
-  k.rows = ws + d.off_rows; k.rowlen = d.rowlen;
+  k.rows = ws + d.off_rows; k.rowlen = d.rowlen; k.ntr = d.ntr;
+  k.perm = reinterpret_cast<const int*>(ws + d.off_meta); k.tcs = k.perm + (size_t)(d.J > 0 ? d.J : 1) * 64;
+  k.aoff = k.tcs + d.ntr; k.tend = k.aoff + d.ntr + 1;
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
   double* MB = lds + (size_t)V_NARR * d.np;    // 4 border-column vectors (A'DA border, then U^-T m_b)
@@ -1443,8 +1534,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       if (i < n) lo[i] = have_x ? aW3[(J + jb) * 64 + lane] / EV[i] : NAN;
     }
     for (int js = 0; js < J; ++js) {
-      const int s = 16 * js + k.c, r = k.q * k.Kq + s;
-      if (s < k.Kq && r < k.m) lo[n + r] = have_x ? aW3[js * 64 + lane] * Fs[js * 64 + lane] : NAN;
+      const int r = k.perm[js * 64 + lane];   // original row of this sorted position
+      if (r >= 0) lo[n + r] = have_x ? aW3[js * 64 + lane] * Fs[js * 64 + lane] : NAN;
     }
   }
   if (have_x && !v_current) {  // objective at the restored point, in the caller's units (H~,g~ scaling is objective preserving)
@@ -1509,6 +1600,106 @@ __global__ void mfma_selftest_kernel(const double* Am, const double* Bm, double*
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+#ifdef QP_PROBE
+// Diagnostic build only: pass 1 alone (same code, no surrounding solver state) to measure what the matrix-core loop
+// costs when the register allocator has nothing else to keep alive.  out[b] = cycles per pass, out[batch+b] = checksum.
+template <int T, int NB> __global__ __launch_bounds__(64) void syrk_probe_kernel(QpParams P, int reps) {
+  const int b = blockIdx.x;
+  Ctx k;
+  const QpDims& d = P.d;
+  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = d.ld;
+  k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
+  double* ws = P.ws + (size_t)b * d.ws_per_qp;
+  k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
+  k.rows = ws + d.off_rows; k.rowlen = d.rowlen; k.ntr = d.ntr;
+  k.perm = reinterpret_cast<const int*>(ws + d.off_meta); k.tcs = k.perm + (size_t)(d.J > 0 ? d.J : 1) * 64;
+  k.aoff = k.tcs + d.ntr; k.tend = k.aoff + d.ntr + 1;
+  extern __shared__ double lds[];
+  k.Ms = nullptr; k.vec = lds;
+  double* MB = lds + (size_t)V_NARR * d.np;
+  for (int js = 0; js < k.JT; ++js) {
+    const int ix = js * 64 + k.lane;
+    rowp(k, R_D)[ix] = 1.0; rowp(k, R_W1)[ix] = 0.5; rowp(k, R_W2)[ix] = 0.25; rowp(k, R_W3)[ix] = 2.0;
+  }
+  __syncthreads();
+  v4d acc[Tri<T>::NT];
+  acc_init<T>(k, acc);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < reps; ++r) {
+    pass_syrk<T, NB>(k, acc, vecp(k, V_P1), vecp(k, V_P2), vecp(k, V_P3), MB);
+    __syncthreads();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  double cs = 0;
+#pragma unroll
+  for (int i = 0; i < Tri<T>::NT; ++i) cs += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  cs = wave_sum(cs);
+  if (k.lane == 0) { P.dump[b] = (double)(t1 - t0) / reps; P.dump[gridDim.x + b] = cs; }
+}
+#endif
+
+#ifdef QP_PROBE
+// Diagnostic build only: the register Cholesky alone.  out[b][0..5] = cycles of: whole reg_factor, T diag_factor calls,
+// T LDS round trips (tile_store + tile_load_t), forward+backward solve of one right-hand-side column.
+template <int T> __global__ __launch_bounds__(64) void factor_probe_kernel(QpParams P, int reps) {
+  const int b = blockIdx.x;
+  Ctx k;
+  const QpDims& d = P.d;
+  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = d.ld;
+  k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
+  double* ws = P.ws + (size_t)b * d.ws_per_qp;
+  k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
+  k.rows = ws + d.off_rows; k.rowlen = d.rowlen; k.ntr = d.ntr;
+  extern __shared__ double lds[];
+  k.Ms = nullptr; k.vec = lds;
+  double* MB = lds + (size_t)V_NARR * d.np;
+  double* SCR = MB + (size_t)4 * d.np;
+  double* YL = SCR + 16 * 17 + 16;
+  v4d acc[Tri<T>::NT], rh[T];
+  unsigned long long tt[4] = {0, 0, 0, 0};
+  double cs = 0;
+  for (int r = 0; r < reps; ++r) {
+    acc_init<T>(k, acc);
+#pragma unroll
+    for (int K = 0; K < T; ++K) {   // make it safely positive definite: add 20 to the diagonal
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { if (k.q + 4 * p == k.c) acc[Tri<T>::idx(K, K)][p] += 20.0; rh[K][p] = 1.0 + k.c; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    reg_factor<T>(k, acc, YL, rh, 1e-30);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    tt[0] += t1 - t0;
+    v4d Yk;
+#pragma unroll
+    for (int K = 0; K < T; ++K) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) { Yk[p] = (k.q + 4 * p == k.c) ? 1.0 : 0.0; if (k.q + 4 * p == k.c) acc[Tri<T>::idx(K, K)][p] += 30.0; }
+      diag_factor(k, acc[Tri<T>::idx(K, K)], Yk, rh[K], 1e-30);
+      cs += Yk[0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    tt[1] += t2 - t1;
+#pragma unroll
+    for (int K = 0; K < T; ++K) { tile_store(k, YL + K * 272, acc[Tri<T>::idx(K, K)]); __syncthreads(); acc[Tri<T>::idx(K, K)] = tile_load_t(k, YL + K * 272); }
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    tt[2] += t3 - t2;
+    reg_forward<T>(k, acc, YL, rh);
+    reg_backward<T>(k, acc, YL, rh, SCR);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long t4 = __builtin_amdgcn_s_memtime();
+    tt[3] += t4 - t3;
+#pragma unroll
+    for (int K = 0; K < T; ++K) cs += rh[K][0] + acc[Tri<T>::idx(K, K)][1];
+  }
+  cs = wave_sum(cs);
+  if (k.lane == 0) { for (int i = 0; i < 4; ++i) P.dump[(size_t)b * 8 + i] = (double)tt[i] / reps; P.dump[(size_t)b * 8 + 4] = cs; }
+}
+#endif
+
 void qp_make_dims(int n, int m, QpDims* d) {
   d->n = n; d->m = m;
   // 1..4 trailing variables (the slack columns of the LTV-MPC QPs: nV = 2N + 1 or 2N + 4) are a *border*: they are
@@ -1524,7 +1715,9 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->ld = n | 1;
   d->rowlen = (d->J + d->JB) * 64;
   size_t off = 0;
-  d->off_Aw = off; off += (size_t)((d->Kq + 1) / 2) * d->T * 128;
+  d->ntr = (d->Kq + 3) / 4;   // trips of 4 k-steps (16 rows)
+  d->off_Aw = off; off += (size_t)(2 * d->ntr) * d->T * 128;   // dense upper bound of the operand stream
+  d->off_meta = off; off += ((size_t)(d->J > 0 ? d->J : 1) * 64 + 2 * (size_t)d->ntr + 1 + 16 + 1) / 2 + 1;   // int arrays: perm, tcs, aoff, tend
   d->off_Hw = off; off += (size_t)d->T * d->T * 4 * 64;
   d->off_gw = off; off += d->np;
   d->off_E = off; off += d->np;
@@ -1536,7 +1729,12 @@ void qp_make_dims(int n, int m, QpDims* d) {
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
   d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272) * sizeof(double);
-  d->lds_prep = ((size_t)d->np + 4 + 16 * (size_t)(4 * d->Kq + 1)) * sizeof(double);
+  d->prep_tw = 16;
+  for (;;) {
+    d->lds_prep = ((size_t)d->np + 4 + (size_t)d->prep_tw * (4 * d->Kq + 1)) * sizeof(double) + ((size_t)4 * d->Kq + 16 * (size_t)d->ntr + 16 + 2 * (size_t)d->ntr + 1 + 3) * sizeof(int);
+    if (d->lds_prep <= 96 * 1024 || d->prep_tw == 2) break;   // keep the staging tile small enough for more than one workgroup per CU
+    d->prep_tw >>= 1;
+  }
 }
 
 template <int T, int NB> static hipError_t launch_solve_TN(const QpParams& P, int batch, hipStream_t st) {
@@ -1565,6 +1763,18 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_mid) { e = hipEventRecord(ev_mid, st); if (e != hipSuccess) return e; }
+#ifdef QP_PROBE
+  if (P.dump && P.dump_stage == 7 && P.d.T == 5) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_probe_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_solve);
+    hipLaunchKernelGGL((factor_probe_kernel<5>), dim3(batch), dim3(64), P.d.lds_solve, st, P, 8);
+    return hipGetLastError();
+  }
+  if (P.dump && P.dump_stage == 8 && P.d.T == 5 && P.d.NB == 1) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_probe_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_solve);
+    hipLaunchKernelGGL((syrk_probe_kernel<5, 1>), dim3(batch), dim3(64), P.d.lds_solve, st, P, 16);
+    return hipGetLastError();
+  }
+#endif
   switch (P.d.T) {
 #ifdef QP_ONLY_T
     case QP_ONLY_T: return launch_solve_T<QP_ONLY_T>(P, batch, st);
