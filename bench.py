@@ -115,8 +115,8 @@ def main():
         "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_job / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: batch=%d independent condensed QPs per GPU, %s model, N=%d, nV=%d, nC=%d, generic mode (dense H,g,A,bounds resident in HBM)"
-                               % (Bl, args.model, N, nV, nC),
+        "config": {"workload": "%s: batch=%d independent condensed QPs per GPU, %s model, N=%d, nV=%d, nC=%d, generic mode (dense H,g,A,bounds resident in HBM)"
+                               % ("BASELINE configs[1]" if (args.model == "kinematic" and N == 40 and Bl == 4096) else "non-headline shape", Bl, args.model, N, nV, nC),
                    "batch_per_gpu": Bl, "global_batch": Btot, "track": "fsg2019", "seed": 20190,
                    "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "solved_total": int(solved_total), "tol_kkt": 1e-8,
                    "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,

@@ -265,6 +265,8 @@ struct Ctx {
   const int* perm; const int* tcs; const int* aoff; const int* tend;   // row order and operand-stream directory (qp_prep_kernel)
   const double* Aw; const double* Hw; const double* Ab; const double* Hb;
   double* rows;  // base of owner-layout row arrays
+  double* ring;  // LDS: operand ring of the streaming passes (records of 1 KB)
+  double* cof;   // LDS: per-slot coefficient staging of the streaming passes ([array][64])
   int rowlen;
   double* Ms;    // LDS n x ld
   double* vec;   // LDS n-vectors, np each
@@ -332,18 +334,89 @@ template <int T> DEVINL void acc_init(const Ctx& k, v4d* acc) {
 
 template <int C> struct IC { static constexpr int value = C; };
 
+// ---------------------------------------------------------------------------------------------
+// Operand stream of the three passes over A~.  The stream is a plain sequence of 1 KB records (one column tile of
+// one pair of k-steps) in exactly the order the passes consume it, so the producer is a linear walk: records go
+// global memory -> LDS by `global_load_lds_dwordx4` (no VGPRs involved, LDS address = M0 + lane*16) into a ring of R
+// records, always D records ahead of the consumer, whatever the tile count of the current trip is.  The consumer
+// reads a record with one ds_read_b128 per lane.  The compiler does not track LDS-DMA -> ds_read dependences, so the
+// ordering is explicit: after topping the lead up to D records beyond the ones about to be consumed,
+// `s_waitcnt vmcnt(D)` guarantees that everything older than the newest D vector-memory operations has landed (any
+// other load or store in between only makes the wait more conservative); the asm memory clobbers keep the compiler
+// from moving LDS reads or DMA issues across the wait.  The ring is drained (vmcnt(0)) before a pass returns.
+// ---------------------------------------------------------------------------------------------
+template <int T> struct StreamCfg {
+  static constexpr int D = T <= 5 ? 6 : (T == 6 ? 4 : (T == 7 ? 3 : 2));   // records in flight beyond the current pair of k-steps
+  static constexpr int R = D + T;                                          // ring capacity
+};
+#define QP_STR2(x) #x
+#define QP_STR(x) QP_STR2(x)
+template <int T> struct Stream {
+  static constexpr int D = StreamCfg<T>::D, R = StreamCfg<T>::R;
+  const char* gnext;   // wave-uniform: global address of the next record to issue
+  int slot_i, slot_e;  // ring slot of the next record to issue / to consume
+  DEVINL void start(const Ctx& k) {
+    gnext = reinterpret_cast<const char*>(k.Aw); slot_i = 0; slot_e = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(k);
+  }
+  DEVINL void issue(const Ctx& k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gnext + k.lane * 16),
+                                     (__attribute__((address_space(3))) void*)(k.ring + slot_i * 128), 16, 0, 0);
+    gnext += 1024;
+    slot_i = slot_i + 1 == R ? 0 : slot_i + 1;
+  }
+  // tops the lead up by C records, waits for the C records of the current pair of k-steps and reads them
+  template <int C> DEVINL void next_pair(const Ctx& k, v2d* b) {
+#pragma unroll
+    for (int t = 0; t < C; ++t) issue(k);
+    if (D == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (D == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (D == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+      int sl = slot_e + t; if (sl >= R) sl -= R;
+      b[t] = *reinterpret_cast<const v2d*>(k.ring + sl * 128 + k.lane * 2);
+    }
+    slot_e += C; if (slot_e >= R) slot_e -= R;
+  }
+  DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+// Per-row coefficients of a pass (owner layout [slot][64] in global memory): one slot (16 k-steps) at a time is staged
+// in LDS -- NA wave-wide loads per 16 k-steps instead of NA broadcast loads per k-step -- and read back as 16-byte
+// pairs (both k-steps of a pair) with the lane group's row as address.
+template <int NA> struct CoefStage {
+  double reg[NA > 0 ? NA : 1];
+  DEVINL void load(const Ctx& k, const double* const* arr, int js) {
+    const int jc = js < k.J ? js : k.J - 1;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) reg[a] = arr[a][jc * 64 + k.lane];
+  }
+  DEVINL void commit(const Ctx& k) {   // registers -> LDS (the previous slot is dead by now)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) k.cof[a * 64 + k.lane] = reg[a];
+  }
+  DEVINL void read_pair(const Ctx& k, int s, v2d* out) const {   // s even: k-steps s, s+1 of lane group q
+#pragma unroll
+    for (int a = 0; a < NA; ++a) out[a] = *reinterpret_cast<const v2d*>(k.cof + a * 64 + k.q * 16 + (s & 15));
+  }
+};
+
 // pass 1: acc += A~' D A~ on the matrix cores; p1 = A~'w1, p2 = A~'w2, p3 = A~'w3 on the VALU beside them.
 // The stream is walked trip by trip (4 k-steps); a trip with tc column tiles only touches the tc(tc+1)/2 accumulator
 // tiles it can reach.  Trips are sorted by tc, so the pass is T phases with compile-time tile counts (phase C: all
-// trips with tc == C) and no branches inside a trip.  The operands of the next trip are in flight while one is
-// consumed (two pairs of k-steps = 2 x tc x 1 KB per wave).
+// trips with tc == C) and no branches inside a trip.
 template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P1, double* P2, double* P3, double* MB) {
   constexpr int NBB = NB > 0 ? NB : 1;
-  const double* D = rowp(k, R_D); const double* W1 = rowp(k, R_W1);
-  const double* W2 = rowp(k, R_W2); const double* W3 = rowp(k, R_W3);
-  const int JS = k.J * 64, ntr = k.ntr;
-  double p1[T], p2[T], p3[T], cq[2][2][4 + NBB];
-  v2d bq[2][T];
+  constexpr int NA = 4 + NB;
+  const int JS = k.J * 64;
+  const double* arr[NA];
+  arr[0] = rowp(k, R_D); arr[1] = rowp(k, R_W1); arr[2] = rowp(k, R_W2); arr[3] = rowp(k, R_W3);
+#pragma unroll
+  for (int e = 0; e < NB; ++e) arr[4 + e] = k.Ab + (size_t)e * JS;
+  double p1[T], p2[T], p3[T];
   double pb[NBB][T], sbb[NBB][NBB], pwb[3][NBB];   // border: column of A'DA, border block, border entries of p1..p3
 #pragma unroll
   for (int t = 0; t < T; ++t) { p1[t] = 0; p2[t] = 0; p3[t] = 0; }
@@ -355,62 +428,43 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
     for (int f = 0; f < NBB; ++f) sbb[e][f] = 0;
     pwb[0][e] = pwb[1][e] = pwb[2][e] = 0;
   }
-  // loads of pair u of trip tr (tc tiles; wave-uniform guards, the tiles beyond tc are never read by that trip's phase)
-  auto issue = [&](int u, int tr) {
-    const int tc = k.tcs[tr];
-    const double* src = k.Aw + ((size_t)k.aoff[tr] + u * tc) * 128 + k.lane * 2;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (t < tc) bq[u][t] = *reinterpret_cast<const v2d*>(src + t * 128);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int s = 4 * tr + 2 * u + h;
-      const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-      cq[u][h][0] = D[ri]; cq[u][h][1] = W1[ri]; cq[u][h][2] = W2[ri]; cq[u][h][3] = W3[ri];
-#pragma unroll
-      for (int e = 0; e < NB; ++e) cq[u][h][4 + e] = k.Ab[(size_t)e * JS + ri];
-    }
-  };
-  if (ntr > 0) { issue(0, 0); issue(1, 0); }
+  Stream<T> st;
+  CoefStage<NA> cs;
   int tr = 0;
-  auto phase = [&](auto Cc) {
+  if (k.ntr > 0) { st.start(k); cs.load(k, arr, 0); }
+  auto phase = [&](auto Cc) __attribute__((always_inline)) {
     constexpr int C = decltype(Cc)::value;
     const int tr_end = k.tend[C];
     for (; tr < tr_end; ++tr) {
-      const int trn = min(tr + 1, ntr - 1);
+      if ((tr & 3) == 0) { cs.commit(k); cs.load(k, arr, (tr >> 2) + 1); }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        double bc[2][C], cf[2][4 + NBB];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-          for (int t = 0; t < C; ++t) bc[h][t] = bq[u][t][h];
-#pragma unroll
-          for (int e = 0; e < 4 + NBB; ++e) cf[h][e] = cq[u][h][e];
-        }
-        issue(u, trn);
+        v2d b[C], cf[NA];
+        st.template next_pair<C>(k, b);
+        cs.read_pair(k, 4 * tr + 2 * u, cf);
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           double a[C], ab[NBB];
-          const double dd = cf[h][0], w1 = cf[h][1], w2 = cf[h][2], w3 = cf[h][3];
+          const double dd = cf[0][h], w1 = cf[1][h], w2 = cf[2][h], w3 = cf[3][h];
 #pragma unroll
-          for (int e = 0; e < NB; ++e) ab[e] = cf[h][4 + e];
+          for (int e = 0; e < NB; ++e) ab[e] = cf[4 + e][h];
 #pragma unroll
-          for (int t = 0; t < C; ++t) a[t] = dd * bc[h][t];
+          for (int t = 0; t < C; ++t) a[t] = dd * b[t][h];
 #pragma unroll
           for (int I = 0; I < C; ++I)
 #pragma unroll
             for (int Jt = I; Jt < C; ++Jt)
-              acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], bc[h][Jt], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
+              acc[Tri<T>::idx(I, Jt)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[Jt][h], acc[Tri<T>::idx(I, Jt)], 0, 0, 0);
 #pragma unroll
           for (int t = 0; t < C; ++t) {
-            p1[t] = fma(w1, bc[h][t], p1[t]); p2[t] = fma(w2, bc[h][t], p2[t]); p3[t] = fma(w3, bc[h][t], p3[t]);
+            p1[t] = fma(w1, b[t][h], p1[t]); p2[t] = fma(w2, b[t][h], p2[t]); p3[t] = fma(w3, b[t][h], p3[t]);
           }
 #pragma unroll
           for (int e = 0; e < NB; ++e) {
             const double dab = dd * ab[e];
 #pragma unroll
-            for (int t = 0; t < C; ++t) pb[e][t] = fma(dab, bc[h][t], pb[e][t]);
+            for (int t = 0; t < C; ++t) pb[e][t] = fma(dab, b[t][h], pb[e][t]);
 #pragma unroll
             for (int f = e; f < NB; ++f) sbb[e][f] = fma(dab, ab[f], sbb[e][f]);
             pwb[0][e] = fma(w1, ab[e], pwb[0][e]); pwb[1][e] = fma(w2, ab[e], pwb[1][e]); pwb[2][e] = fma(w3, ab[e], pwb[2][e]);
@@ -427,6 +481,7 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
   if constexpr (T >= 6) phase(IC<6>{});
   if constexpr (T >= 7) phase(IC<7>{});
   if constexpr (T >= 8) phase(IC<8>{});
+  if (k.ntr > 0) st.drain();
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     double v1 = q_sum(p1[t]), v2 = q_sum(p2[t]), v3 = q_sum(p3[t]);
@@ -451,11 +506,18 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
 // direction; as soon as a row's va = a_r' dxa is reduced, the second-order weight
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
+// FUSE 3 is the polish step (see the kernel).  Same operand stream and phase structure as pass 1.
 template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor, double* Pcor2 = nullptr) {
   constexpr int NBB = NB > 0 ? NB : 1;
-  const int JS = k.J * 64, ntr = k.ntr;
-  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], pd[FUSE >= 2 ? T : 1], pdb[NBB], cq[2][2][6 + NBB];
-  v2d bq[2][T];
+  constexpr int NC = FUSE == 1 ? 6 : (FUSE >= 2 ? 3 : 0);   // per-row coefficient arrays of the fused part
+  constexpr int NA = NC + NB;
+  const int JS = k.J * 64;
+  const double* arr[NA > 0 ? NA : 1];
+  if (FUSE == 1) { arr[0] = rowp(k, R_RPL); arr[1] = rowp(k, R_CB1); arr[2] = rowp(k, R_CC1); arr[3] = rowp(k, R_RPU); arr[4] = rowp(k, R_CB2); arr[5] = rowp(k, R_CC2); }
+  if (FUSE >= 2) { arr[0] = rowp(k, R_CB1); arr[1] = rowp(k, R_RPL); arr[2] = rowp(k, R_CC1); }   // polish: rho*act, target b, multiplier y
+#pragma unroll
+  for (int f = 0; f < NB; ++f) arr[NC + f] = k.Ab + (size_t)f * JS;
+  double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], pd[FUSE >= 2 ? T : 1], pdb[NBB];
 #pragma unroll
   for (int e = 0; e < NVEC; ++e) {
 #pragma unroll
@@ -469,45 +531,24 @@ template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, c
   for (int f = 0; f < NBB; ++f) { pcb[f] = 0.0; pdb[f] = 0.0; }
 #pragma unroll
   for (int t = 0; t < (FUSE >= 2 ? T : 1); ++t) pd[t] = 0.0;
-  const double* CA1 = rowp(k, R_RPL); const double* CB1 = rowp(k, R_CB1); const double* CC1 = rowp(k, R_CC1);
-  const double* CA2 = rowp(k, R_RPU); const double* CB2 = rowp(k, R_CB2); const double* CC2 = rowp(k, R_CC2);
-  auto issue = [&](int u, int tr) {   // same ring as pass 1: the next trip is in flight while one is consumed
-    const int tc = k.tcs[tr];
-    const double* src = k.Aw + ((size_t)k.aoff[tr] + u * tc) * 128 + k.lane * 2;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (t < tc) bq[u][t] = *reinterpret_cast<const v2d*>(src + t * 128);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int s = 4 * tr + 2 * u + h;
-      const int ri = (s >> 4) * 64 + k.q * 16 + (s & 15);
-      if (FUSE == 1) { cq[u][h][0] = CA1[ri]; cq[u][h][1] = CB1[ri]; cq[u][h][2] = CC1[ri]; cq[u][h][3] = CA2[ri]; cq[u][h][4] = CB2[ri]; cq[u][h][5] = CC2[ri]; }
-      if (FUSE >= 2) { cq[u][h][0] = CB1[ri]; cq[u][h][1] = CA1[ri]; cq[u][h][2] = CC1[ri]; }   // polish: rho*act, target b, multiplier y
-#pragma unroll
-      for (int f = 0; f < NB; ++f) cq[u][h][6 + f] = k.Ab[(size_t)f * JS + ri];
-    }
-  };
-  if (ntr > 0) { issue(0, 0); issue(1, 0); }
   double keep[NVEC + 1];   // last entry: the updated multiplier of the polish modes (written to rout[NVEC])
 #pragma unroll
   for (int e = 0; e < NVEC + 1; ++e) keep[e] = 0.0;
+  Stream<T> st;
+  CoefStage<NA> cs;
   int tr = 0;
-  auto phase = [&](auto Cc) {
+  if (k.ntr > 0) { st.start(k); if (NA > 0) cs.load(k, arr, 0); }
+  auto phase = [&](auto Cc) __attribute__((always_inline)) {
     constexpr int C = decltype(Cc)::value;
     const int tr_end = k.tend[C];
     for (; tr < tr_end; ++tr) {
-      const int trn = min(tr + 1, ntr - 1);
+      if (NA > 0 && (tr & 3) == 0) { cs.commit(k); cs.load(k, arr, (tr >> 2) + 1); }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        double bc[2][C], cf[2][6 + NBB];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-          for (int t = 0; t < C; ++t) bc[h][t] = bq[u][t][h];
-#pragma unroll
-          for (int e = 0; e < 6 + NBB; ++e) cf[h][e] = cq[u][h][e];
-        }
-        issue(u, trn);
+        v2d b[C], cf[NA > 0 ? NA : 1];
+        st.template next_pair<C>(k, b);
+        if (NA > 0) cs.read_pair(k, 4 * tr + 2 * u, cf);
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int s = 4 * tr + 2 * u + h;
@@ -516,30 +557,30 @@ template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, c
           for (int e = 0; e < NVEC; ++e) {
             double dsum = 0.0;
 #pragma unroll
-            for (int t = 0; t < C; ++t) dsum = fma(bc[h][t], v[e][t], dsum);
+            for (int t = 0; t < C; ++t) dsum = fma(b[t][h], v[e][t], dsum);
             dsum = grp16_sum(dsum);
 #pragma unroll
-            for (int f = 0; f < NB; ++f) dsum = fma(cf[h][6 + f], vb[e][f], dsum);
+            for (int f = 0; f < NB; ++f) dsum = fma(cf[NC + f][h], vb[e][f], dsum);
             if (k.c == cc) keep[e] = dsum;
             if (FUSE >= 2 && e == 0) {   // polish: pen = rho*act*(v - b), y^ = y - pen; accumulate A~'y^ and A~'pen
-              const double pen = cf[h][0] * (dsum - cf[h][1]);
-              const double ynew = cf[h][2] - pen;
+              const double pen = cf[0][h] * (dsum - cf[1][h]);
+              const double ynew = cf[2][h] - pen;
               if (k.c == cc) keep[NVEC] = ynew;
 #pragma unroll
-              for (int t = 0; t < C; ++t) { pc[t] = fma(ynew, bc[h][t], pc[t]); pd[t] = fma(pen, bc[h][t], pd[t]); }
+              for (int t = 0; t < C; ++t) { pc[t] = fma(ynew, b[t][h], pc[t]); pd[t] = fma(pen, b[t][h], pd[t]); }
 #pragma unroll
-              for (int f = 0; f < NB; ++f) { pcb[f] = fma(ynew, cf[h][6 + f], pcb[f]); pdb[f] = fma(pen, cf[h][6 + f], pdb[f]); }
+              for (int f = 0; f < NB; ++f) { pcb[f] = fma(ynew, cf[NC + f][h], pcb[f]); pdb[f] = fma(pen, cf[NC + f][h], pdb[f]); }
             }
             if (FUSE == 1 && e == 0) {
-              const double dl_ = dsum + cf[h][0], du_ = cf[h][3] - dsum;
-              const double w = dl_ * fma(cf[h][2], dl_, cf[h][1]) - du_ * fma(cf[h][5], du_, cf[h][4]);
+              const double dl_ = dsum + cf[0][h], du_ = cf[3][h] - dsum;
+              const double w = dl_ * fma(cf[2][h], dl_, cf[1][h]) - du_ * fma(cf[5][h], du_, cf[4][h]);
 #pragma unroll
-              for (int t = 0; t < C; ++t) pc[t] = fma(w, bc[h][t], pc[t]);
+              for (int t = 0; t < C; ++t) pc[t] = fma(w, b[t][h], pc[t]);
 #pragma unroll
-              for (int f = 0; f < NB; ++f) pcb[f] = fma(w, cf[h][6 + f], pcb[f]);
+              for (int f = 0; f < NB; ++f) pcb[f] = fma(w, cf[NC + f][h], pcb[f]);
             }
           }
-          if (cc == 15 || s + 1 == 4 * ntr) {
+          if (cc == 15 || s + 1 == 4 * k.ntr) {
             const int js = s >> 4;
 #pragma unroll
             for (int e = 0; e < NVEC; ++e) { rout[e][js * 64 + k.lane] = keep[e]; keep[e] = 0.0; }
@@ -557,6 +598,7 @@ template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, c
   if constexpr (T >= 6) phase(IC<6>{});
   if constexpr (T >= 7) phase(IC<7>{});
   if constexpr (T >= 8) phase(IC<8>{});
+  if (k.ntr > 0) st.drain();
   if (FUSE) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -821,6 +863,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   double* MB = lds + (size_t)V_NARR * d.np;    // 4 border-column vectors (A'DA border, then U^-T m_b)
   double* SCR = MB + (size_t)4 * d.np;          // 16 x 17 tile-transpose scratch
   double* YL = SCR + 16 * 17 + 16;              // T resident tiles U_KK^-T
+  k.ring = YL + T * 272;                        // operand ring of the streaming passes
+  k.cof = k.ring + StreamCfg<T>::R * 128;       // coefficient staging, (6 + NB) arrays of 64
   const double* gw = ws + d.off_gw;
   const double* Es = ws + d.off_E;
   const double* Fs = ws + d.off_F;
@@ -855,7 +899,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #define aRPU rowp(k, R_RPU)
 
   // Hx = H~ x: core through the tile grid, border columns (full-length vectors Hb[b]) on the VALU
-  auto hx_full = [&](const double* XV) {
+  auto hx_full = [&](const double* XV) __attribute__((always_inline)) {
     hx_tiles<T>(k, XV, HX);
     if (NB > 0) {
       __syncthreads();
@@ -989,7 +1033,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   double Ubb[NBB][NBB]; // Cholesky factor of the border Schur complement (wave-uniform scalars)
   // border part of a solve: R holds y_c = U^-T b_c (core) and b_b (border); leaves the border solution in R[nc+e]
   // and y_c - sum_e u_e x_e in the core, ready for the backward sweep
-  auto border_solve = [&](double* R) {
+  auto border_solve = [&](double* R) __attribute__((always_inline)) {
     if (NB > 0) {
       double yb[NBB], xb[NBB];
 #pragma unroll
@@ -1027,7 +1071,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   };
   // M = (acc from pass 1) + diag(aD on the variable rows), border columns = H~ border + A'DA border (MB); factorise in
   // registers and solve for the two right-hand sides in R1, R2 (in place).  Returns 1 on a non-finite pivot.
-  auto factor_solve2 = [&](int it_now) -> int {
+  auto factor_solve2 = [&](int it_now) __attribute__((always_inline)) -> int {
     double dmax_l = 0;
 #pragma unroll
     for (int K = 0; K < T; ++K) {
@@ -1115,7 +1159,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     return 0;
   };
   // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place)
-  auto solve1 = [&](double* V) {
+  auto solve1 = [&](double* V) __attribute__((always_inline)) {
     const double* vin[1] = {V}; double* vout[1] = {V};
     rhs_load<T, 1>(k, rh, vin);
     reg_forward<T>(k, acc, YL, rh);
@@ -1617,6 +1661,7 @@ template <int T, int NB> __global__ __launch_bounds__(64) void syrk_probe_kernel
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
   double* MB = lds + (size_t)V_NARR * d.np;
+  k.ring = MB + (size_t)4 * d.np + 16 * 17 + 16 + T * 272; k.cof = k.ring + StreamCfg<T>::R * 128;
   for (int js = 0; js < k.JT; ++js) {
     const int ix = js * 64 + k.lane;
     rowp(k, R_D)[ix] = 1.0; rowp(k, R_W1)[ix] = 0.5; rowp(k, R_W2)[ix] = 0.25; rowp(k, R_W3)[ix] = 2.0;
@@ -1655,6 +1700,7 @@ template <int T> __global__ __launch_bounds__(64) void factor_probe_kernel(QpPar
   double* MB = lds + (size_t)V_NARR * d.np;
   double* SCR = MB + (size_t)4 * d.np;
   double* YL = SCR + 16 * 17 + 16;
+  k.ring = YL + T * 272; k.cof = k.ring + StreamCfg<T>::R * 128;
   v4d acc[Tri<T>::NT], rh[T];
   unsigned long long tt[4] = {0, 0, 0, 0};
   double cs = 0;
@@ -1728,7 +1774,10 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->off_save = off; off += d->np + d->rowlen;
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
-  d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272) * sizeof(double);
+  {
+    const int Tt = d->T, Dd = Tt <= 5 ? 6 : (Tt == 6 ? 4 : (Tt == 7 ? 3 : 2));   // = StreamCfg<T>::D
+    d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272 + (size_t)(Dd + Tt) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);
+  }
   d->prep_tw = 16;
   for (;;) {
     d->lds_prep = ((size_t)d->np + 4 + (size_t)d->prep_tw * (4 * d->Kq + 1)) * sizeof(double) + ((size_t)4 * d->Kq + 16 * (size_t)d->ntr + 16 + 2 * (size_t)d->ntr + 1 + 3) * sizeof(int);
