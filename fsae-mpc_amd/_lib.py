@@ -30,7 +30,7 @@ class Spline(C.Structure):
 
 
 class LtvDesc(C.Structure):
-    _fields_ = [("model", C.c_int), ("N", C.c_int), ("batch", C.c_int), ("dt", C.c_double)]
+    _fields_ = [("model", C.c_int), ("N", C.c_int), ("batch", C.c_int), ("dt", C.c_double), ("integrator", C.c_int)]
 
 
 class FsaempcError(RuntimeError):

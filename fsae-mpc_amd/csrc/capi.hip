@@ -179,6 +179,7 @@ static int ltv_check(const fsaempc_ltv_desc* d, const fsaempc_spline* sp) {
   if (!d || !sp || !sp->xP || !sp->yP) return fail(FSAEMPC_ERR_ARG, "null argument");
   if (d->model != FSAEMPC_MODEL_KINEMATIC && d->model != FSAEMPC_MODEL_DYNAMIC) return fail(FSAEMPC_ERR_ARG, "unknown model");
   if (d->N <= 0 || d->batch < 0 || !(d->dt > 0) || sp->M <= 0 || !(sp->dl > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  if (d->integrator < FSAEMPC_INT_DEFAULT || d->integrator > FSAEMPC_INT_RK4) return fail(FSAEMPC_ERR_ARG, "unknown integrator");
   if (ltv_build_lds_bytes(fsaempc_ltv_nx(d->model), d->N, 256) > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "horizon too long for the LDS staging");
   return 0;
 }
@@ -192,6 +193,7 @@ int fsaempc_ltv_build_qp_batch_device(const fsaempc_ltv_desc* desc, const fsaemp
   if (desc->batch == 0) return 0;
   LtvParams P; memset(&P, 0, sizeof(P));
   P.nx = fsaempc_ltv_nx(desc->model); P.N = desc->N; P.dt = desc->dt;
+  P.integ = desc->integrator >= 0 ? desc->integrator : (desc->model == FSAEMPC_MODEL_KINEMATIC ? FSAEMPC_INT_RK2 : FSAEMPC_INT_RK4);   // ltvmpc_*.m:38
   P.spM = sp->M; P.spdl = sp->dl; P.xP = sp->xP; P.yP = sp->yP;
   P.x0 = x0; P.x_ref = x_ref; P.x_lin = x_lin; P.u_lin = u_lin;
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA; P.pred = pred; P.Bt = Bt; P.qconst = qconst;

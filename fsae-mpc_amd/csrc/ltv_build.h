@@ -4,7 +4,7 @@
 #include <stddef.h>
 
 struct LtvParams {
-  int nx, N;
+  int nx, N, integ;   // integ: 0 Euler, 1 RK2 (midpoint), 2 RK4
   double dt;
   int spM; double spdl; const double* xP; const double* yP;   // spline table (device)
   const double *x0, *x_ref, *x_lin, *u_lin;

@@ -160,15 +160,21 @@ template <int NX> DEVINL void model_A(const double* x, const Spl& sp, double* A)
 }
 
 // Linearise step k about (xi, ui): writes Ad = I + dt*A, Bd = dt*B, dd = dt*d   (sequential_integration.m:16-18)
-template <int NX> DEVINL void linearise_step(const double* xi, const double* ui, const Spl& sp, double dt,
+// integ: 0 Euler (euler_*_curvilinear.m:24-30), 1 midpoint rule (rk2_*_curvilinear.m:25-50), 2 classical RK4
+// (rk4_*_curvilinear.m:25-59).  The reference drivers use rk2 for the kinematic and rk4 for the dynamic model
+// (ltvmpc_kinetmatic_curvilinear.m:38, ltvmpc_dynamic_curvilinear.m:38); the others are the alternates kept beside them.
+template <int NX> DEVINL void linearise_step(const double* xi, const double* ui, const Spl& sp, double dt, int integ,
                                              double* Ad, double* Bd, double* dd) {
   constexpr int NN = NX * NX;
   double Bc[NX * 2];
   for (int i = 0; i < NX * 2; ++i) Bc[i] = 0.0;
   Bc[3] = 1.0; Bc[(NX - 1) + NX] = 1.0;  // B_curv_kin.m:12-16 / B_curv_dyn.m:12-18
   double f[NX], Ai[NN], Bi[NX * 2];
-  if (NX == 5) {
-    // rk2_kinematic_curvilinear.m:25-50 (midpoint rule)
+  if (integ == 0) {
+    model_f<NX>(xi, ui, sp, f);
+    model_A<NX>(xi, sp, Ai);
+    for (int j = 0; j < NX * 2; ++j) Bi[j] = Bc[j];
+  } else if (integ == 1) {
     double k1[NX], xs[NX], F1[NN], F2[NN], Tm[NN], TB[NX * 2];
     model_f<NX>(xi, ui, sp, k1);
     for (int j = 0; j < NX; ++j) xs[j] = xi[j] + k1[j] * dt / 2;
@@ -181,7 +187,6 @@ template <int NX> DEVINL void linearise_step(const double* xi, const double* ui,
     mmul<NX>(F2, Bc, TB, 2);
     for (int j = 0; j < NX * 2; ++j) Bi[j] = Bc[j] + TB[j] * dt / 2;
   } else {
-    // rk4_dynamic_curvilinear.m:25-59
     double k1[NX], k2[NX], k3[NX], k4[NX], xs[NX];
     double F[NN], K[NN], Tm[NN], Ks[NN], U[NX * 2], Us[NX * 2], TB[NX * 2];
     model_f<NX>(xi, ui, sp, k1);
@@ -260,7 +265,7 @@ template <int NX> __global__ __launch_bounds__(256) void ltv_build_kernel(LtvPar
 
   // ---- 1. linearise every step (one thread per step) ----
   for (int k = tid; k < N; k += nth)
-    linearise_step<NX>(x_lin + (size_t)k * NX, u_lin + (size_t)k * 2, sp, dt, Ad + (size_t)k * NN, Bd + (size_t)k * NX * 2, dd + (size_t)k * NX);
+    linearise_step<NX>(x_lin + (size_t)k * NX, u_lin + (size_t)k * 2, sp, dt, P.integ, Ad + (size_t)k * NN, Bd + (size_t)k * NX * 2, dd + (size_t)k * NX);
   // zero Bt while the linearisation runs
   for (size_t i = tid; i < (size_t)R * nV; i += nth) Bt[i] = 0.0;
   __syncthreads();

@@ -21,7 +21,7 @@ class LtvBatch:
     """Device-resident batched LTV-MPC step (one call = linearise + condense + solve + post-solve for
     `batch` independent instances).  Inputs/outputs are torch tensors on the GPU."""
 
-    def __init__(self, model, N, dt, track, batch, device="cuda:0", options=None):
+    def __init__(self, model, N, dt, track, batch, device="cuda:0", options=None, integrator=-1):
         import torch
         self.torch = torch
         self.model, self.N, self.dt, self.batch = model, N, float(dt), batch
@@ -30,7 +30,7 @@ class LtvBatch:
         self.track = track
         self.xP, self.yP = track.device(self.device)
         self.sp = Spline(track.M, track.dl, C.c_void_p(self.xP.data_ptr()), C.c_void_p(self.yP.data_ptr()))
-        self.desc = LtvDesc(model, N, batch, self.dt)
+        self.desc = LtvDesc(model, N, batch, self.dt, integrator)   # integrator: -1 reference default, 0 Euler, 1 RK2, 2 RK4
         self.opts = options if options is not None else default_opts()
         self._ws = None
         self._qp = None

@@ -118,11 +118,17 @@ typedef struct {
   const double* yP;
 } fsaempc_spline;
 
+#define FSAEMPC_INT_DEFAULT (-1)  /* the one the reference driver calls: RK2 kinematic, RK4 dynamic (ltvmpc_*.m:38) */
+#define FSAEMPC_INT_EULER 0       /* mpc/ltv/{kinematic,dynamic}/euler_*_curvilinear.m:24-30 */
+#define FSAEMPC_INT_RK2   1       /* rk2_*_curvilinear.m:25-50 (midpoint rule) */
+#define FSAEMPC_INT_RK4   2       /* rk4_*_curvilinear.m:25-59 */
+
 typedef struct {
   int model;     /* FSAEMPC_MODEL_* */
   int N;         /* horizon steps (main.m:36) */
   int batch;
   double dt;     /* main.m:37 */
+  int integrator; /* FSAEMPC_INT_*: lineariser of the continuous model (the reference keeps all three per model) */
 } fsaempc_ltv_desc;
 
 int fsaempc_ltv_nx(int model);            /* 5 / 7 */

@@ -150,6 +150,29 @@ def test_construction_parity(fm, torch_, orc, model, N, B):
     assert relerr(q["pred"].cpu().numpy(), pred) <= 1e-9
 
 
+@pytest.mark.parametrize("model,integ", [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2)])
+def test_alternate_integrators(fm, torch_, orc, model, integ):
+    """The reference keeps three linearisers per model (euler_/rk2_/rk4_*_curvilinear.m); the drivers call rk2
+    (kinematic) / rk4 (dynamic).  All of them, through the C ABI's `integrator` field, against the oracle."""
+    torch = torch_
+    N, B = 12, 5
+    tr = fm.Track.load("fss2019"); otr = orc.Track.load(fm.tracks._HERE + "/tracks/fss2019.json")
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 77, range(B))
+    q = fm.LtvBatch(model, N, 0.05, tr, B, integrator=integ).build_qp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul))
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = orc.build_qp(model, otr, N, 0.05, x0[b], xr[b].T, xl[b].T, ul[b].T, integrator=integ)
+        assert relerr(q["H"][b].cpu().numpy().T, ref["H"]) <= 1e-9
+        assert relerr(q["A"][b].cpu().numpy().T, ref["A"]) <= 1e-9
+        for k in ("g", "lb", "ub", "lbA", "ubA"):
+            assert relerr(q[k][b].cpu().numpy(), ref[k]) <= 1e-9, k
+        assert abs(q["const"][b].item() - ref["const"]) <= 1e-9 * max(1.0, abs(ref["const"]))
+    if integ == (1 if model == 0 else 2):   # the default (-1) is the driver's choice
+        q2 = fm.LtvBatch(model, N, 0.05, tr, B).build_qp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul))
+        torch.cuda.synchronize()
+        assert torch.equal(q2["H"], q["H"]) and torch.equal(q2["A"], q["A"])
+
+
 @pytest.mark.parametrize("model,N,B", [(0, 40, 512), (0, 20, 128), (1, 40, 96), (1, 60, 24)])
 def test_solve_parity_generic_mode(fm, torch_, orc, model, N, B):
     """Identical (H,g,A,bounds) to the oracle and to the HIP solver (generic mode of SURVEY 8d)."""
