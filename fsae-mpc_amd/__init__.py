@@ -5,9 +5,11 @@ from . import _lib
 from ._lib import FsaempcError, default_opts, lib
 from .ltvmpc import LtvBatch, dims, ltvmpc_dynamic_curvilinear, ltvmpc_kinetmatic_curvilinear
 from .qpoases import qp_solve_batch_device, qpOASES, qpOASES_sequence
+from .reference import obtain_reference, obtain_reference_batch_device, reference_live_batch_device
 from .synthetic import DYNAMIC, KINEMATIC, instances, reference_live
 from .tracks import Track
 
 __all__ = ["FsaempcError", "default_opts", "lib", "LtvBatch", "dims", "ltvmpc_dynamic_curvilinear",
            "ltvmpc_kinetmatic_curvilinear", "qp_solve_batch_device", "qpOASES", "qpOASES_sequence", "DYNAMIC", "KINEMATIC",
-           "instances", "reference_live", "Track"]
+           "instances", "reference_live", "Track", "obtain_reference", "obtain_reference_batch_device",
+           "reference_live_batch_device"]

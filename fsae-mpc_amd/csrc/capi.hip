@@ -10,6 +10,7 @@
 #include "fsaempc.h"
 #include "qp_solver.h"
 #include "ltv_build.h"
+#include "reference.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -246,6 +247,24 @@ int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_sp
   hipError_t e = ltv_post_launch(fsaempc_ltv_nx(desc->model), desc->N, ltv_ns(desc->model), desc->batch, D(c.z), D(c.pred), D(c.Bt), D(c.qc),
                                  u_opt, x_opt, slack, fval, (hipStream_t)stream);
   if (e != hipSuccess) return hipfail(e, "ltv_post_launch");
+  return 0;
+}
+
+int fsaempc_obtain_reference_batch_device(const double* plan, double ds, int N_s, const double* t, const double* s0, double dt,
+                                          int N_t, int batch, double* x_ref, void* stream) {
+  if (!plan || !t || !s0 || !x_ref) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (N_s <= 0 || N_t <= 0 || batch < 0 || !(ds > 0) || !(dt > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  RefParams P; P.plan = plan; P.t = t; P.s0 = s0; P.x_ref = x_ref; P.ds = ds; P.dt = dt; P.N_s = N_s; P.N_t = N_t; P.batch = batch;
+  hipError_t e = obtain_reference_launch(P, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "obtain_reference_launch");
+  return 0;
+}
+
+int fsaempc_reference_live_batch_device(int nx, int N, double dt, double target_vel, int batch, const double* x0, double* x_ref, void* stream) {
+  if (!x0 || !x_ref) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if ((nx != 5 && nx != 7) || N <= 0 || batch < 0 || !(dt > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  hipError_t e = reference_live_launch(nx, N, dt, target_vel, batch, x0, x_ref, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "reference_live_launch");
   return 0;
 }
 

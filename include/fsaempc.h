@@ -161,6 +161,27 @@ int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_sp
                                   double* u_opt, double* x_opt, double* slack, double* fval, int* exitflag, int* iter,
                                   void* workspace, long long workspace_bytes, void* stream);
 
+/* ---- reference trajectories ---------------------------------------------------------------- */
+
+/*
+ * Replaces x_ref = obtain_reference(x, ds, N_s, t, s0, dt, N_t)   (util/obtain_reference.m:1-48; call site
+ * main.m:115, commented in the live loop), batched over s0.  plan: the planner vector x (8 values per s-cell:
+ * n, mu, x_d, y_d, theta_d, delta, a, delta_d; obtain_reference.m:7-15), t: per-cell traversal times (N_s),
+ * s0: `batch` arc-length positions.  Output per instance: x_ref 7 x N_t column-major, row 1 =
+ * s0 + mod(idx+rto-idx_1-rto_1, N_s)*ds, rows 2..7 linear interpolation of the six planner states.
+ * Device pointers, asynchronous on `stream`.
+ */
+int fsaempc_obtain_reference_batch_device(const double* plan, double ds, int N_s, const double* t,
+                                          const double* s0, double dt, int N_t, int batch,
+                                          double* x_ref, void* stream);
+
+/*
+ * Replaces the live reference generator of main.m:107-114 (velocity ramp +-10 m/s^2 clipped at target_vel,
+ * s_ref = s0 + cumsum(v_ref*dt), all other states 0), batched.  x0: batch x nx, x_ref: batch x (nx x N).
+ */
+int fsaempc_reference_live_batch_device(int nx, int N, double dt, double target_vel, int batch,
+                                        const double* x0, double* x_ref, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 const char* fsaempc_last_error(void);
 /* Runs the on-device fp64 MFMA layout self-test (v_mfma_f64_16x16x4_f64 operand / accumulator

@@ -203,6 +203,15 @@ def reference_live(nx, N, dt, x0, target_vel=20.0):
     return x_ref
 
 
+def obtain_reference(x, ds, N_s, t, s0, dt, N_t):
+    """util/obtain_reference.m: planner vector x (8*N_s), per-cell times t (N_s) -> x_ref (7, N_t)."""
+    x, t = _f(x).ravel(), _f(t).ravel()
+    assert x.size == 8 * N_s and t.size == N_s
+    x_ref = np.zeros((7, N_t), order="F")
+    lib().orc_obtain_reference(_p(x), C.c_double(ds), N_s, _p(t), C.c_double(s0), C.c_double(dt), N_t, _p(x_ref))
+    return x_ref
+
+
 def synth_instances(model, N, dt, L, seed, ids):
     """SURVEY 8(d) synthetic instances -> x0 (B,nx), x_lin (B,nx,N)F per instance, u_lin, x_ref (batch-major)."""
     nx = dims(model, N)[0]

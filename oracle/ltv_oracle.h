@@ -108,6 +108,8 @@ int orc_ltv_step(int model, int N, double dt, const orc_spline* sp,
 
 /* main.m:107-114 live reference generator (TARGET_VEL ramp); x_ref nx x N zero-filled then rows 1 and 4 set */
 void orc_reference_live(int nx, int N, double dt, double target_vel, const double* x0, double* x_ref);
+/* util/obtain_reference.m:5-48: x = planner vector (8 per cell), t = per-cell times; x_ref 7 x N_t column-major */
+void orc_obtain_reference(const double* x, double ds, int N_s, const double* t, double s0, double dt, int N_t, double* x_ref);
 
 /* SURVEY 8(d) synthetic instances: splitmix64 keyed by seed ^ (id*0x9E3779B97F4A7C15) */
 void orc_synth_instance(int model, int N, double dt, double L, unsigned long long seed, unsigned long long id,

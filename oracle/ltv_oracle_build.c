@@ -517,6 +517,35 @@ void orc_reference_live(int nx, int N, double dt, double target_vel, const doubl
   }
 }
 
+/* ---- util/obtain_reference.m:5-48 ------------------------------------------ */
+static int nxt1(int i, int N) { return (i % N) + 1; }                       /* nxt(): mod(i, N) + 1, 1-based (:55-57) */
+static double mmod(double a, double b) { return a - floor(a / b) * b; }     /* MATLAB mod, b > 0 */
+void orc_obtain_reference(const double* x, double ds, int N_s, const double* t, double s0, double dt, int N_t, double* x_ref) {
+  const double L = ds * N_s;                                                /* :5 */
+  int* idx = (int*)malloc(sizeof(int) * (N_t + 2));
+  double* rto = (double*)malloc(sizeof(double) * (N_t + 2));
+  idx[1] = (int)floor(mmod(s0, L) / ds) + 1;                                /* :21 */
+  rto[1] = mmod(mmod(s0, L) / ds, 1.0);                                     /* :22 */
+  for (int i = 2; i <= N_t + 1; ++i) {                                      /* :24-35 */
+    double t_remaining = dt;
+    idx[i] = idx[i - 1];
+    rto[i] = rto[i - 1] + t_remaining / t[idx[i] - 1];
+    t_remaining = t_remaining - t[idx[i - 1] - 1] * (1 - rto[i - 1]);
+    while (rto[i] > 1) {
+      idx[i] = nxt1(idx[i], N_s);
+      rto[i] = t_remaining / t[idx[i] - 1];
+      t_remaining = t_remaining - t[idx[i] - 1];
+    }
+  }
+  for (int i = 2; i <= N_t + 1; ++i) {                                      /* :40-48 */
+    double* col = x_ref + (size_t)(i - 2) * 7;
+    const int a = idx[i] - 1, b = nxt1(idx[i], N_s) - 1;
+    col[0] = s0 + mmod(idx[i] + rto[i] - idx[1] - rto[1], (double)N_s) * ds;
+    for (int c = 0; c < 6; ++c) col[1 + c] = x[8 * a + c] + (x[8 * b + c] - x[8 * a + c]) * rto[i];
+  }
+  free(idx); free(rto);
+}
+
 /* ---- SURVEY 8(d) synthetic instances -------------------------------------- */
 static unsigned long long sm64_next(unsigned long long* s) {
   unsigned long long z = (*s += 0x9E3779B97F4A7C15ULL);

@@ -318,3 +318,33 @@ def test_edge_cases(fm, torch_):
         assert abs(f - fo) <= FVAL_TOL * max(1, abs(fo)) and np.max(np.abs(x - xo)) <= 1e-5 * max(1, np.abs(xo).max())
     with pytest.raises(fm.FsaempcError):
         fm.qpOASES(np.eye(130), np.zeros(130), np.zeros(130), np.ones(130))   # > FSAEMPC_MAX_NV fails loudly
+
+
+def test_obtain_reference_parity(fm, torch_, orc):
+    """util/obtain_reference.m on the device (batched over s0) against the oracle: same operations in the same
+    order, so the results are bit-identical; plus the mirror with the reference's own signature."""
+    torch = torch_
+    rng = np.random.default_rng(11)
+    N_s, N_t, dt, ds = 400, 40, 0.05, 0.5
+    x = rng.normal(size=8 * N_s); x[2::8] = rng.uniform(5, 25, N_s)
+    t = ds / x[2::8]
+    s0 = np.concatenate([[0.0, 199.999999, 200.0, 1234.5], rng.uniform(0, 1000, 252)])
+    out = fm.obtain_reference_batch_device(_dev(torch, x), ds, N_s, _dev(torch, t), _dev(torch, s0), dt, N_t)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for b in range(len(s0)):
+        ref = orc.obtain_reference(x, ds, N_s, t, s0[b], dt, N_t)
+        assert np.array_equal(out[b].T, ref), b
+    assert np.array_equal(fm.obtain_reference(x, ds, N_s, t, 3.7, dt, N_t), orc.obtain_reference(x, ds, N_s, t, 3.7, dt, N_t))
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_reference_live_parity(fm, torch_, orc, model):
+    """main.m:107-114 on the device against the oracle and the host generator used for the synthetic instances."""
+    torch = torch_
+    N, B = 40, 64
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, 300.0, 5, range(B))
+    x0[::7, 3] = 27.5                                   # above TARGET_VEL: ramp down
+    got = fm.reference_live_batch_device(_dev(torch, x0), N, 0.05).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b].T, orc.reference_live(x0.shape[1], N, 0.05, x0[b])), b

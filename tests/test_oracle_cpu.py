@@ -184,3 +184,52 @@ def test_reference_live_generator(orc):
     assert np.allclose(xr[3], [19.7, 20, 20, 20]) and np.allclose(xr[0], 3.0 + np.cumsum(xr[3] * 0.05)) and np.all(xr[[1, 2, 4]] == 0)
     xr = orc.reference_live(5, 3, 0.05, np.array([0, 0, 0, 21.0, 0]))
     assert np.allclose(xr[3], [20.5, 20, 20])
+
+
+def _obtain_reference_numpy(x, ds, N_s, t, s0, dt, N_t):
+    """Independent restatement of util/obtain_reference.m with 1-based index arithmetic spelled out."""
+    L = ds * N_s
+    cols = [x[c::8] for c in range(6)]
+    idx = np.zeros(N_t + 2, dtype=int); rto = np.zeros(N_t + 2)
+    idx[1] = int(np.floor(np.mod(s0, L) / ds)) + 1
+    rto[1] = np.mod(np.mod(s0, L) / ds, 1)
+    nxt = lambda i: (i % N_s) + 1
+    for i in range(2, N_t + 2):
+        rem = dt
+        idx[i] = idx[i - 1]
+        rto[i] = rto[i - 1] + rem / t[idx[i] - 1]
+        rem = rem - t[idx[i - 1] - 1] * (1 - rto[i - 1])
+        while rto[i] > 1:
+            idx[i] = nxt(idx[i]); rto[i] = rem / t[idx[i] - 1]; rem = rem - t[idx[i] - 1]
+    out = np.zeros((7, N_t))
+    for i in range(2, N_t + 2):
+        out[0, i - 2] = s0 + np.mod(idx[i] + rto[i] - idx[1] - rto[1], N_s) * ds
+        for c in range(6):
+            a, b = cols[c][idx[i] - 1], cols[c][nxt(idx[i]) - 1]
+            out[1 + c, i - 2] = a + (b - a) * rto[i]
+    return out
+
+
+def _plan_table(N_s, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(size=8 * N_s)
+    x[2::8] = rng.uniform(5, 25, N_s)           # x_d > 0
+    ds = 0.5
+    t = ds / x[2::8]                            # per-cell traversal time of a planner solution
+    return x, ds, t
+
+
+@pytest.mark.parametrize("s0", [0.0, 3.7, 123.456, 2 * 0.5 * 400 + 1.25, 199.999999])
+def test_obtain_reference_restatement_and_properties(orc, s0):
+    N_s, N_t, dt = 400, 40, 0.05
+    x, ds, t = _plan_table(N_s, 5)
+    ref = _obtain_reference_numpy(x, ds, N_s, t, s0, dt, N_t)
+    got = orc.obtain_reference(x, ds, N_s, t, s0, dt, N_t)
+    assert np.array_equal(got, ref)
+    # the s row advances monotonically and starts ahead of s0
+    assert (np.diff(got[0]) > 0).all() and got[0, 0] > s0
+    # a plan with constant cell times t = ds/v walks exactly v*dt per step
+    x2 = x.copy(); x2[2::8] = 10.0; t2 = np.full(N_s, ds / 10.0)
+    g2 = orc.obtain_reference(x2, ds, N_s, t2, s0, dt, N_t)
+    assert np.allclose(g2[0], s0 + 10.0 * dt * np.arange(1, N_t + 1), rtol=0, atol=1e-9)
+    assert np.allclose(g2[3], 10.0)
