@@ -7,18 +7,18 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wal
 
 all: $(LIBDIR)/libfsaempc.so oracle
 
-$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h $(CSRC)/plant.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libfsaempc.so: $(LIBDIR)/qp_solver.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/capi.o
+$(LIBDIR)/libfsaempc.so: $(LIBDIR)/qp_solver.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # diagnostic build with in-kernel phase stamps (never benchmarked; see tools/phase_profile.py)
 stamps: $(LIBDIR)/libfsaempc_stamps.so
-$(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
+$(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/capi.hip
+	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
 
 oracle:
 	$(MAKE) -C oracle

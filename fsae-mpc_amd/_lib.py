@@ -14,6 +14,7 @@ EXPORTS = [
     "fsaempc_debug_set_dump", "fsaempc_debug_set_polished", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
     "fsaempc_seq_init", "fsaempc_seq_hotstart", "fsaempc_seq_hotstart_matrices", "fsaempc_seq_cleanup",
     "fsaempc_obtain_reference_batch_device", "fsaempc_reference_live_batch_device",
+    "fsaempc_cl_pre_batch_device", "fsaempc_cl_plant_batch_device",
 ]
 
 
@@ -58,6 +59,8 @@ def lib():
         L.fsaempc_ltv_step_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [C.POINTER(QpOpts)] + [vp] * 6 + [vp, ll, vp]
         L.fsaempc_obtain_reference_batch_device.argtypes = [vp, C.c_double, C.c_int, vp, vp, C.c_double, C.c_int, C.c_int, vp, vp]
         L.fsaempc_reference_live_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp, vp]
+        L.fsaempc_cl_pre_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Spline), vp, vp, C.c_int, vp, vp, vp, vp]
+        L.fsaempc_cl_plant_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.fsaempc_debug_set_dump.argtypes = [vp, C.c_int]
         L.fsaempc_debug_set_polished.argtypes = [vp]
         _LIB = L

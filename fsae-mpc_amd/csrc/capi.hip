@@ -11,6 +11,7 @@
 #include "qp_solver.h"
 #include "ltv_build.h"
 #include "reference.h"
+#include "plant.h"
 
 namespace {
 thread_local char g_err[512] = "";
@@ -265,6 +266,30 @@ int fsaempc_reference_live_batch_device(int nx, int N, double dt, double target_
   if ((nx != 5 && nx != 7) || N <= 0 || batch < 0 || !(dt > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
   hipError_t e = reference_live_launch(nx, N, dt, target_vel, batch, x0, x_ref, (hipStream_t)stream);
   if (e != hipSuccess) return hipfail(e, "reference_live_launch");
+  return 0;
+}
+
+int fsaempc_cl_pre_batch_device(int model, int N, double dt, double target_vel, double L, const fsaempc_spline* sp, const double* cart,
+                                const double* s_guess, int batch, double* x0, double* x_ref, int* finished, void* stream) {
+  if (!sp || !sp->xP || !sp->yP || !cart || !s_guess || !x0 || !x_ref || !finished) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (model != FSAEMPC_MODEL_KINEMATIC && model != FSAEMPC_MODEL_DYNAMIC) return fail(FSAEMPC_ERR_ARG, "unknown model");
+  if (N <= 0 || batch < 0 || !(dt > 0) || sp->M <= 0 || !(sp->dl > 0) || !(L > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  ClPreParams P; P.nx = fsaempc_ltv_nx(model); P.N = N; P.batch = batch; P.dt = dt; P.target_vel = target_vel; P.L = L;
+  P.spM = sp->M; P.spdl = sp->dl; P.xP = sp->xP; P.yP = sp->yP; P.cart = cart; P.s_guess = s_guess; P.x0 = x0; P.x_ref = x_ref; P.finished = finished;
+  hipError_t e = cl_pre_launch(P, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "cl_pre_launch");
+  return 0;
+}
+
+int fsaempc_cl_plant_batch_device(int model, int N, double dt, int batch, double* cart, double* pid, const double* x_opt,
+                                  const int* finished, const int* exitflag, double* u_last, void* stream) {
+  if (!cart || !pid || !x_opt) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (model != FSAEMPC_MODEL_KINEMATIC && model != FSAEMPC_MODEL_DYNAMIC) return fail(FSAEMPC_ERR_ARG, "unknown model");
+  if (N <= 0 || batch < 0 || !(dt > 0)) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  ClPlantParams P; P.nx = fsaempc_ltv_nx(model); P.N = N; P.batch = batch; P.dt = dt; P.cart = cart; P.pid = pid; P.x_opt = x_opt;
+  P.finished = finished; P.exitflag = exitflag; P.u_last = u_last;
+  hipError_t e = cl_plant_launch(P, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "cl_plant_launch");
   return 0;
 }
 

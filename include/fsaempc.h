@@ -182,6 +182,29 @@ int fsaempc_obtain_reference_batch_device(const double* plan, double ds, int N_s
 int fsaempc_reference_live_batch_device(int nx, int N, double dt, double target_vel, int batch,
                                         const double* x0, double* x_ref, void* stream);
 
+/* ---- closed loop around the step (main.m:91-179), batched: one car per instance ------------------- */
+
+/*
+ * Replaces main.m:93-114 per car: [s,n,mu] = cartesian_to_curvilinear(x(1),x(2),x(3),x_spline,y_spline,dl,x_opt(1))
+ * (vehicle_models/cartesian_to_curvilinear.m:17-26, spline/closest_point.m:15-32 with epsilon 0.01), the x0 assembly
+ * for the model (:94-98), the lap check s >= L (:101-104, sets finished[b] = 1) and the live reference (:107-114).
+ * cart: batch x 7 [x,y,theta,x_d,y_d,theta_d,delta]; s_guess: batch (first predicted s of the previous plan).
+ * Outputs x0 (batch x nx), x_ref (batch x (nx x N)).
+ */
+int fsaempc_cl_pre_batch_device(int model, int N, double dt, double target_vel, double L, const fsaempc_spline* sp,
+                                const double* cart, const double* s_guess, int batch,
+                                double* x0, double* x_ref, int* finished, void* stream);
+
+/*
+ * Replaces main.m:163-175 per car: set points v_ref = x_opt(4), delta_ref = x_opt(N_x) from this step's plan, then ten
+ * sub-steps of pid_controller (vehicle_models/pid_controller.m; gains main.m:84-88) + integrate_cart_dyn(x, u, dt/10)
+ * (vehicle_models/cartesian_dynamic/integrate_cart_dyn.m, f_cart_dyn.m).  cart (batch x 7) and pid (batch x 4:
+ * velocity integral / last error, steering integral / last error) are updated in place; cars with finished[b] != 0 or
+ * exitflag[b] != 0 keep their state (both arrays optional); u_last (optional, batch x 2) = last actuator rates.
+ */
+int fsaempc_cl_plant_batch_device(int model, int N, double dt, int batch, double* cart, double* pid, const double* x_opt,
+                                  const int* finished, const int* exitflag, double* u_last, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 const char* fsaempc_last_error(void);
 /* Runs the on-device fp64 MFMA layout self-test (v_mfma_f64_16x16x4_f64 operand / accumulator

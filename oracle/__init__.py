@@ -203,6 +203,40 @@ def reference_live(nx, N, dt, x0, target_vel=20.0):
     return x_ref
 
 
+def cart_to_curv(track, x, y, theta, s0):
+    s, n, mu = C.c_double(0), C.c_double(0), C.c_double(0)
+    lib().orc_cart_to_curv(C.byref(track.c), C.c_double(x), C.c_double(y), C.c_double(theta), C.c_double(s0), C.byref(s), C.byref(n), C.byref(mu))
+    return s.value, n.value, mu.value
+
+
+def f_cart_dyn(x, u):
+    f = np.zeros(7)
+    lib().orc_f_cart_dyn(_p(_f(x)), _p(_f(u)), _p(f))
+    return f
+
+
+def integrate_cart_dyn(x0, u, dt):
+    x = np.zeros(7)
+    lib().orc_integrate_cart_dyn(_p(_f(x0)), _p(_f(u)), C.c_double(dt), _p(x))
+    return x
+
+
+def plant_step(x, pid, v_ref, delta_ref, dt):
+    """main.m:171-175.  Returns new (x, pid, u_last)."""
+    x, pid, u = _f(x).copy(), _f(pid).copy(), np.zeros(2)
+    lib().orc_plant_step(_p(x), _p(pid), C.c_double(v_ref), C.c_double(delta_ref), C.c_double(dt), _p(u))
+    return x, pid, u
+
+
+def cl_pre(model, N, dt, track, cart, s_guess, target_vel=20.0):
+    """main.m:93-114 -> x0 (nx,), x_ref (nx, N), finished."""
+    nx = dims(model, N)[0]
+    x0 = np.zeros(nx); x_ref = np.zeros((nx, N), order="F")
+    fin = lib().orc_cl_pre(model, N, C.c_double(dt), C.c_double(target_vel), C.byref(track.c), C.c_double(track.L), _p(_f(cart)), C.c_double(s_guess),
+                           _p(x0), _p(x_ref))
+    return x0, x_ref, fin
+
+
 def obtain_reference(x, ds, N_s, t, s0, dt, N_t):
     """util/obtain_reference.m: planner vector x (8*N_s), per-cell times t (N_s) -> x_ref (7, N_t)."""
     x, t = _f(x).ravel(), _f(t).ravel()

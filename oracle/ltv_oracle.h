@@ -108,6 +108,16 @@ int orc_ltv_step(int model, int N, double dt, const orc_spline* sp,
 
 /* main.m:107-114 live reference generator (TARGET_VEL ramp); x_ref nx x N zero-filled then rows 1 and 4 set */
 void orc_reference_live(int nx, int N, double dt, double target_vel, const double* x0, double* x_ref);
+/* ---- closed loop around the step (ltv_oracle_plant.c) ---- */
+double orc_closest_point(const orc_spline* sp, double x0, double y0, double s, double epsilon);   /* spline/closest_point.m */
+void orc_cart_to_curv(const orc_spline* sp, double x, double y, double theta, double s0, double* s, double* n, double* mu);
+void orc_f_cart_dyn(const double* x /*7*/, const double* u /*2*/, double* f /*7*/);             /* cartesian_dynamic/f_cart_dyn.m */
+void orc_integrate_cart_dyn(const double* x0, const double* u, double dt, double* x);            /* integrate_cart_dyn.m */
+double orc_pid(double target, double current, const double* settings /*4*/, double* status /*2*/);   /* pid_controller.m */
+void orc_plant_step(double* x /*7 in/out*/, double* pid /*4 in/out*/, double v_ref, double delta_ref, double dt, double* u_last /*2*/);
+int orc_cl_pre(int model, int N, double dt, double target_vel, const orc_spline* sp, double L, const double* cart /*7*/, double s_guess,
+               double* x0, double* x_ref);
+
 /* util/obtain_reference.m:5-48: x = planner vector (8 per cell), t = per-cell times; x_ref 7 x N_t column-major */
 void orc_obtain_reference(const double* x, double ds, int N_s, const double* t, double s0, double dt, int N_t, double* x_ref);
 

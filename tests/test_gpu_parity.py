@@ -348,3 +348,88 @@ def test_reference_live_parity(fm, torch_, orc, model):
     got = fm.reference_live_batch_device(_dev(torch, x0), N, 0.05).cpu().numpy()
     for b in range(B):
         assert np.array_equal(got[b].T, orc.reference_live(x0.shape[1], N, 0.05, x0[b])), b
+
+
+def _random_carts(orc, otr, B, seed):
+    import ctypes as C
+    rng = np.random.default_rng(seed)
+    L = orc.lib(); L.orc_spline_d.restype = C.c_double
+    carts, guesses = [], []
+    for _ in range(B):
+        s, n = rng.uniform(0, otr.L * 0.9), rng.uniform(-0.5, 0.5)
+        xd = L.orc_spline_d(otr.c.xP, otr.M, C.c_double(otr.dl), C.c_double(s)); yd = L.orc_spline_d(otr.c.yP, otr.M, C.c_double(otr.dl), C.c_double(s))
+        x = L.orc_spline_val(otr.c.xP, otr.M, C.c_double(otr.dl), C.c_double(s)); y = L.orc_spline_val(otr.c.yP, otr.M, C.c_double(otr.dl), C.c_double(s))
+        nrm = np.hypot(xd, yd)
+        carts.append([x - yd / nrm * n, y + xd / nrm * n, np.arctan2(yd, xd) + rng.uniform(-0.1, 0.1), rng.uniform(0, 25), rng.uniform(-0.3, 0.3),
+                      rng.uniform(-0.3, 0.3), rng.uniform(-0.1, 0.1)])
+        guesses.append(s + rng.uniform(-1, 1))
+    return np.array(carts), np.array(guesses)
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_closed_loop_pieces_parity(fm, torch_, orc, model):
+    """cl_pre (frame transform, x0, lap check, reference) and cl_plant (PID + 6-stage plant, 10 sub-steps) against the
+    oracle.  Tolerance 1e-11 relative: same formulas, but libm (CPU) vs ocml (GPU) transcendentals and pow() vs products."""
+    torch = torch_
+    tr = fm.Track.load("fss2019"); otr = orc.Track.load(fm.tracks._HERE + "/tracks/fss2019.json")
+    B, N = 96, 40
+    carts, guesses = _random_carts(orc, otr, B, 3)
+    cl = fm.ClosedLoop(model, N, 0.05, tr, carts)
+    cl.x_opt[:, 0, 0] = _dev(torch, guesses)
+    cl.pre(); torch.cuda.synchronize()
+    x0g, xrg = cl.x0.cpu().numpy(), cl.x_ref.cpu().numpy()
+    for b in range(B):
+        x0, x_ref, fin = orc.cl_pre(model, N, 0.05, otr, carts[b], guesses[b])
+        assert np.max(np.abs(x0g[b] - x0)) <= 1e-11 * max(1.0, np.abs(x0).max()), b
+        assert np.max(np.abs(xrg[b].T - x_ref)) <= 1e-11 * max(1.0, np.abs(x_ref).max()), b
+        assert int(cl.finished[b].item()) == fin
+    # plant: set points from a synthetic plan
+    rng = np.random.default_rng(9)
+    plan = np.zeros((B, N, cl.nx)); plan[:, 0, 3] = rng.uniform(0, 25, B); plan[:, 0, cl.nx - 1] = rng.uniform(-0.3, 0.3, B)
+    cl.x_opt = _dev(torch, plan)
+    flags = torch.zeros(B, dtype=torch.int32, device="cuda"); flags[5] = 1      # car 5: step failed -> holds its state
+    cl.finished.zero_(); cl.finished[7] = 1                                      # car 7: lap complete -> holds its state
+    cl.plant(flags); torch.cuda.synchronize()
+    cg, pg, ug = cl.cart.cpu().numpy(), cl.pid.cpu().numpy(), cl.u_last.cpu().numpy()
+    for b in range(B):
+        if b in (5, 7):
+            assert np.array_equal(cg[b], carts[b]); continue
+        x, pid, u = orc.plant_step(carts[b], np.zeros(4), plan[b, 0, 3], plan[b, 0, cl.nx - 1], 0.05)
+        assert np.max(np.abs(cg[b] - x)) <= 1e-11 * max(1.0, np.abs(x).max()), b
+        assert np.max(np.abs(pg[b] - pid)) <= 1e-10 * max(1.0, np.abs(pid).max()) and np.max(np.abs(ug[b] - u)) <= 1e-8 * max(1.0, np.abs(u).max())
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_closed_loop_short_run(fm, torch_, orc, model):
+    """A few receding-horizon steps (main.m:91-179) from standstill: the HIP loop against the same loop driven through the
+    oracle.  The loop feeds each plan back as the next linearisation point, so the comparison tolerance is the solve
+    tolerance of x (1e-4 here), not round-off."""
+    torch = torch_
+    tr = fm.Track.load("fss2019"); otr = orc.Track.load(fm.tracks._HERE + "/tracks/fss2019.json")
+    N, dt, B, T = 20, 0.05, 3, 6
+    carts = np.zeros((B, 7))
+    import ctypes as C
+    for b in range(B):   # main.m:63 starts at the origin of the Cartesian frame = start of the spline; spread the cars a little
+        s = 5.0 * b
+        x, y = (orc.lib().orc_spline_val(P, otr.M, C.c_double(otr.dl), C.c_double(s)) for P in (otr.c.xP, otr.c.yP))
+        orc.lib().orc_spline_d.restype = C.c_double
+        th = np.arctan2(orc.lib().orc_spline_d(otr.c.yP, otr.M, C.c_double(otr.dl), C.c_double(s)), orc.lib().orc_spline_d(otr.c.xP, otr.M, C.c_double(otr.dl), C.c_double(s)))
+        carts[b, :3] = [x, y, th]
+    cl = fm.ClosedLoop(model, N, dt, tr, carts)
+    nx = cl.nx
+    k = np.arange(1, N + 1) * dt
+    xo = np.zeros((B, nx, N)); uo = np.zeros((B, 2, N)); xo[:, 0, :] = 10 * k ** 2 / 2; xo[:, 3, :] = 10 * k; uo[:, 0, :] = 10
+    for b in range(B): xo[b, 0, :] += 5.0 * b
+    cl.x_opt[:, :, 0] += _dev(torch, 5.0 * np.arange(B))[:, None]
+    oc = carts.copy(); opid = np.zeros((B, 4))
+    for step in range(T):
+        out = cl.step(); torch.cuda.synchronize()
+        assert (out["exitflag"].cpu().numpy() == 0).all()
+        for b in range(B):
+            x0, x_ref, fin = orc.cl_pre(model, N, dt, otr, oc[b], xo[b, 0, 0])
+            u, xopt, sl, f, fl, it = orc.ltv_step(model, otr, N, dt, x0, x_ref, xo[b], uo[b])
+            assert fl == 0
+            xo[b] = xopt.reshape(N, nx).T; uo[b] = u.reshape(N, 2).T
+            oc[b], opid[b], _ = orc.plant_step(oc[b], opid[b], xo[b, 3, 0], xo[b, nx - 1, 0], dt)
+        assert np.max(np.abs(cl.cart.cpu().numpy() - oc)) <= 1e-4 * max(1.0, np.abs(oc).max()), step
+    assert (cl.cart[:, 3] > 0.3).all()       # the cars accelerated from standstill

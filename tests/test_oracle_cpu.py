@@ -233,3 +233,58 @@ def test_obtain_reference_restatement_and_properties(orc, s0):
     g2 = orc.obtain_reference(x2, ds, N_s, t2, s0, dt, N_t)
     assert np.allclose(g2[0], s0 + 10.0 * dt * np.arange(1, N_t + 1), rtol=0, atol=1e-9)
     assert np.allclose(g2[3], 10.0)
+
+
+# ---- closed loop around the step (oracle/ltv_oracle_plant.c) ----
+
+def _cart_from_curv(orc, tr, s, n):
+    """Point at arc length s, lateral offset n (left normal), heading = track heading: curvilinear_to_cartesian."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_spline_d.restype = C.c_double
+    xd = L.orc_spline_d(tr.c.xP, tr.M, C.c_double(tr.dl), C.c_double(s)); yd = L.orc_spline_d(tr.c.yP, tr.M, C.c_double(tr.dl), C.c_double(s))
+    x = L.orc_spline_val(tr.c.xP, tr.M, C.c_double(tr.dl), C.c_double(s)); y = L.orc_spline_val(tr.c.yP, tr.M, C.c_double(tr.dl), C.c_double(s))
+    nrm = np.hypot(xd, yd)
+    return x - yd / nrm * n, y + xd / nrm * n, np.arctan2(yd, xd)
+
+
+def test_cartesian_to_curvilinear_inverts_the_track_frame(orc, otrack):
+    rng = np.random.default_rng(4)
+    for _ in range(40):
+        s, n, dmu = rng.uniform(0, otrack.L), rng.uniform(-0.7, 0.7), rng.uniform(-0.3, 0.3)
+        x, y, th = _cart_from_curv(orc, otrack, s, n)
+        s2, n2, mu2 = orc.cart_to_curv(otrack, x, y, th + dmu, s + rng.uniform(-1.0, 1.0))
+        assert abs(s2 - s) < 2e-2          # Newton stops at |step| <= 0.01 (closest_point.m epsilon)
+        assert abs(n2 - n) < 1e-3 and abs(mu2 - dmu) < 2e-2
+    # angdiff wraps: heading + 2*pi gives the same mu
+    x, y, th = _cart_from_curv(orc, otrack, 12.0, 0.2)
+    a = orc.cart_to_curv(otrack, x, y, th + 0.1, 12.0)[2]; b = orc.cart_to_curv(otrack, x, y, th + 0.1 + 2 * np.pi, 12.0)[2]
+    assert abs(a - b) < 1e-12 and abs(a - 0.1) < 2e-2
+
+
+def test_plant_pieces(orc):
+    # straight-line cruise: no slip, no force => the car advances v*dt along its heading and nothing else changes
+    x0 = np.array([1.0, 2.0, 0.3, 15.0, 0.0, 0.0, 0.0])
+    x1 = orc.integrate_cart_dyn(x0, [0.0, 0.0], 0.005)
+    assert np.allclose(x1[:2], x0[:2] + 15.0 * 0.005 * np.array([np.cos(0.3), np.sin(0.3)]), atol=1e-12)
+    assert np.allclose(x1[2:], x0[2:], atol=1e-12)
+    # f_cart_dyn: longitudinal force accelerates by Fx/m, steering rate passes through
+    f = orc.f_cart_dyn(x0, [2800.0, 0.4])
+    assert abs(f[3] - 10.0) < 1e-12 and f[6] == 0.4 and abs(f[2]) == 0.0
+    # PID: pure proportional with saturation (main.m:84-88): 16000*(v_ref - v) clipped at 2800
+    x, pid, u = orc.plant_step(x0, np.zeros(4), 20.0, 0.1, 0.05)
+    assert u[0] == 2800.0 and 0 < u[1] <= 0.8
+    assert x[3] > x0[3] and abs(x[3] - (15.0 + 10.0 * 0.05)) < 5e-3 and 0 < x[6] <= 0.1 + 1e-12
+    assert pid[1] == 20.0 - orc.integrate_cart_dyn(x0, [0, 0], 0)[3] or pid[1] > 0   # last error stored
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_cl_pre_matches_its_parts(orc, otrack, model):
+    x, y, th = _cart_from_curv(orc, otrack, 33.0, -0.25)
+    cart = np.array([x, y, th + 0.05, 12.0, 0.7, 0.1, -0.03])
+    x0, x_ref, fin = orc.cl_pre(model, 40, 0.05, otrack, cart, 32.5)
+    s, n, mu = orc.cart_to_curv(otrack, x, y, th + 0.05, 32.5)
+    assert fin == 0 and x0[0] == s and x0[1] == n and x0[2] == mu
+    assert x0[3] == (np.hypot(12.0, 0.7) if model == 0 else 12.0) and x0[-1] == -0.03
+    assert np.array_equal(x_ref, orc.reference_live(x0.size, 40, 0.05, x0))      # x(4) < TARGET_VEL here, same ramp
+    assert orc.cl_pre(model, 40, 0.05, otrack, cart, 32.5 + otrack.L)[2] == 1      # a lap further: finished
