@@ -81,6 +81,7 @@ __global__ void cl_pre_kernel(ClPreParams P) {
   if (nx == 5) { x0[3] = sqrt(c[3] * c[3] + c[4] * c[4]); x0[4] = c[6]; }   // main.m:95
   else { x0[3] = c[3]; x0[4] = c[4]; x0[5] = c[5]; x0[6] = c[6]; }           // main.m:97
   if (s >= P.L) P.finished[b] = 1;                                           // main.m:101-104
+  if (!(fabs(s) < INFINITY)) P.finished[b] = 2;                              // frame transform lost the track (Newton diverged): the car is out
   double cum = 0.0;
   for (int k = 0; k < N; ++k) {                                              // main.m:107-114
     for (int j = 0; j < nx; ++j) xr[k * nx + j] = 0.0;

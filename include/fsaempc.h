@@ -187,7 +187,8 @@ int fsaempc_reference_live_batch_device(int nx, int N, double dt, double target_
 /*
  * Replaces main.m:93-114 per car: [s,n,mu] = cartesian_to_curvilinear(x(1),x(2),x(3),x_spline,y_spline,dl,x_opt(1))
  * (vehicle_models/cartesian_to_curvilinear.m:17-26, spline/closest_point.m:15-32 with epsilon 0.01), the x0 assembly
- * for the model (:94-98), the lap check s >= L (:101-104, sets finished[b] = 1) and the live reference (:107-114).
+ * for the model (:94-98), the lap check s >= L (:101-104, sets finished[b] = 1; 2 = the closest-point search diverged,
+ * the car left the track) and the live reference (:107-114).
  * cart: batch x 7 [x,y,theta,x_d,y_d,theta_d,delta]; s_guess: batch (first predicted s of the previous plan).
  * Outputs x0 (batch x nx), x_ref (batch x (nx x N)).
  */
