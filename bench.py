@@ -103,6 +103,28 @@ def main():
     n_ok = shard.max_over_ranks(float(-solved), device=rdev)  # min over ranks via max of negatives
     solved_total = shard.sum_over_ranks(float(solved), device=rdev)
     mean_it = float(iters.mean())
+    # SURVEY 8(d) extras, rank 0's shard, outside the timed region: iteration / status histograms and the worst relative
+    # KKT residual of the returned (x, lambda), evaluated with torch on the device (plumbing, not the product path)
+    it_hist = {int(k_): int(c_) for k_, c_ in zip(*np.unique(iters, return_counts=True))}
+    fl_hist = {int(k_): int(c_) for k_, c_ in zip(*np.unique(flags, return_counts=True))}
+    chk = fm.qp_solve_batch_device(*qp_args, workspace=ws, want_lambda=True)
+    torch.cuda.synchronize(dev)
+    Hm, gv, Am, lbv, ubv, lbAv, ubAv = qp_args
+    xs, lam = chk["x"], chk["lam"]
+    AT = Am.transpose(1, 2)                                   # (B, nC, nV): A is stored column-major nC x nV per instance
+    Hx = torch.bmm(Hm, xs.unsqueeze(2)).squeeze(2)
+    Ax = torch.bmm(AT, xs.unsqueeze(2)).squeeze(2)
+    r_d = Hx + gv - lam[:, :nV] - torch.bmm(Am, lam[:, nV:].unsqueeze(2)).squeeze(2)
+    sc_d = torch.clamp(torch.maximum(gv.abs().amax(1), Hx.abs().amax(1)), min=1.0)
+    v = torch.cat([xs, Ax], 1); lo_ = torch.cat([lbv, lbAv], 1); hi_ = torch.cat([ubv, ubAv], 1)
+    fin_lo, fin_hi = lo_ > -1e9, hi_ < 1e9
+    viol = torch.maximum(torch.where(fin_lo, lo_ - v, torch.zeros_like(v)), torch.where(fin_hi, v - hi_, torch.zeros_like(v))).clamp(min=0)
+    sc_p = torch.clamp(v.abs().amax(1), min=1.0)
+    fv = chk["fval"].abs().clamp(min=1.0)
+    comp = torch.where(lam > 0, lam * torch.where(fin_lo, v - lo_, torch.zeros_like(v)), -lam * torch.where(fin_hi, hi_ - v, torch.zeros_like(v))).abs()
+    kkt = torch.stack([r_d.abs().amax(1) / sc_d, viol.amax(1) / sc_p, comp.amax(1) / fv], 1)
+    okm = chk["exitflag"] == 0
+    kkt_max = [float(t) for t in kkt[okm].amax(0).cpu()] if bool(okm.any()) else [float("nan")] * 3
     value = solved_total * args.steps / t_job                  # an instance counts only if its exit flag is 0
     flops_iter = 2.0 * nC * nV * nV + nV ** 3 / 3.0 + 4.0 * nC * nV + 2.0 * nV * nV
     flops_launch = flops_iter * mean_it * Bl
@@ -120,6 +142,8 @@ def main():
                    "batch_per_gpu": Bl, "global_batch": Btot, "track": "fsg2019", "seed": 20190,
                    "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "solved_total": int(solved_total), "tol_kkt": 1e-8,
                    "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,
+                   "iteration_histogram_rank0": it_hist, "exitflag_histogram_rank0": fl_hist,
+                   "max_rel_kkt_rank0": {"stationarity": kkt_max[0], "primal": kkt_max[1], "complementarity": kkt_max[2]},
                    "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
         "roofline": {"bound": "mfma", "kernel": "qp_solve_kernel<%d, %d>" % ((nV // 16, 1 if nV % 16 == 1 else 4) if (nV >= 16 and 1 <= nV % 16 <= 4) else ((nV + 15) // 16, 0)), "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,

@@ -73,6 +73,25 @@ class LtvBatch:
         return out
 
 
+    def sqp(self, x0, x_ref, x_lin, u_lin, sweeps=3, stream=None):
+        """Re-linearisation (SQP) sweeps of SURVEY 8 f-3: the step is solved, its plan becomes the next linearisation point
+        (what main.m:121-125 does from one MPC period to the next, here within one period), `sweeps` times.  Instances
+        whose QP fails keep their previous linearisation point.  Returns the last step's outputs plus `du` = list of
+        per-sweep (B,) tensors max|u_opt - u_lin| (how far each sweep still moved)."""
+        torch = self.torch
+        B, N, nx = self.batch, self.N, self.nx
+        xl, ul = x_lin.reshape(B, N * nx).clone(), u_lin.reshape(B, 2 * N).clone()
+        du, out = [], None
+        for _ in range(sweeps):
+            out = self.step(x0, x_ref, xl, ul, stream=stream)
+            ok = (out["exitflag"] == 0).view(-1, 1)
+            du.append(torch.where(ok.view(-1), (out["u_opt"] - ul).abs().amax(1), torch.full((B,), float("nan"), dtype=torch.float64, device=self.device)))
+            xl = torch.where(ok, out["x_opt"], xl).contiguous()
+            ul = torch.where(ok, out["u_opt"], ul).contiguous()
+        out["du"] = du
+        return out
+
+
 def _single(model, x0, x_ref, track, dt, x_lin, u_lin, QP, device):
     import torch
     x_ref = np.asarray(x_ref, dtype=np.float64)

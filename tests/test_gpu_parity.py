@@ -433,3 +433,32 @@ def test_closed_loop_short_run(fm, torch_, orc, model):
             oc[b], opid[b], _ = orc.plant_step(oc[b], opid[b], xo[b, 3, 0], xo[b, nx - 1, 0], dt)
         assert np.max(np.abs(cl.cart.cpu().numpy() - oc)) <= 1e-4 * max(1.0, np.abs(oc).max()), step
     assert (cl.cart[:, 3] > 0.3).all()       # the cars accelerated from standstill
+
+
+@pytest.mark.parametrize("model", [0, 1])
+def test_sqp_sweeps(fm, torch_, orc, model):
+    """Re-linearisation sweeps against the same loop through the oracle; the sweeps contract."""
+    torch = torch_
+    tr = fm.Track.load("fsg2019"); otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
+    N, B, K = 20, 6, 3
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 31, range(B))
+    out = fm.LtvBatch(model, N, 0.05, tr, B).sqp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul), sweeps=K)
+    torch.cuda.synchronize()
+    assert (out["exitflag"].cpu().numpy() == 0).all()
+    du = np.stack([d.cpu().numpy() for d in out["du"]])
+    # plain re-linearisation has no step control (the reference has no SQP at all): most instances contract, a
+    # bang-bang one may keep flipping an input between its bounds
+    assert np.median(du[-1] / du[0]) <= 0.5, du
+    checked = 0
+    for b in range(B):
+        xlb, ulb = xl[b].T.copy(), ul[b].T.copy()
+        for _ in range(K):
+            u_prev = ulb
+            u, xo, sl, f, fl, it = orc.ltv_step(model, otr, N, 0.05, x0[b], xr[b].T, xlb, ulb)
+            assert fl == 0
+            xlb, ulb = xo.reshape(N, -1).T, u.reshape(N, 2).T
+        if np.abs(ulb - u_prev).max() > 1.0:
+            continue                                   # still moving by more than 1: not a converged comparison point
+        checked += 1
+        assert np.max(np.abs(out["u_opt"][b].cpu().numpy() - u)) <= 1e-3 * max(1.0, np.abs(u).max()), b
+    assert checked >= B // 2
