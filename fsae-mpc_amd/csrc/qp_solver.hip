@@ -32,6 +32,14 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define DEVINL __device__ __forceinline__
+// The solve kernel runs one wavefront per workgroup: its lanes exchange data through LDS (and their own rows of global
+// memory) in program order, and the hardware keeps the DS / vector-memory operations of one wave in order, so a
+// workgroup barrier (s_barrier + full s_waitcnt drain) is not needed -- a compiler-level fence is.
+#ifndef QP_FULL_BARRIERS
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define WAVE_SYNC() __syncthreads()
+#endif
 
 namespace {
 
@@ -672,10 +680,10 @@ DEVINL v4d mfma4_new(const v4d& X, const v4d& Y) {  // X' Y
 
 // tile transpose through the LDS scratch: returns Z with Z[row][col] = X[col][row] (C/D layout both sides)
 DEVINL v4d tile_transpose(const Ctx& k, double* scratch, const v4d& Xt) {
-  __syncthreads();
+  WAVE_SYNC();
 #pragma unroll
   for (int p = 0; p < 4; ++p) scratch[(k.q + 4 * p) * 17 + k.c] = Xt[p];
-  __syncthreads();
+  WAVE_SYNC();
   v4d Z;
 #pragma unroll
   for (int p = 0; p < 4; ++p) Z[p] = scratch[k.c * 17 + k.q + 4 * p];
@@ -763,7 +771,7 @@ template <int T, int K> struct FactorStep {
     for (int p = 0; p < 4; ++p) Yk[p] = (k.q + 4 * p == k.c) ? 1.0 : 0.0;
     int bad = diag_factor(k, acc[Tri<T>::idx(K, K)], Yk, rh[K], floor_abs);
     tile_store(k, YL + K * 272, Yk);          // U_KK^-T stays in LDS for the solves of this iteration
-    __syncthreads();
+    WAVE_SYNC();
     const v4d Wk = tile_load_t(k, YL + K * 272);   // U_KK^-1
 #pragma unroll
     for (int Jt = K + 1; Jt < T; ++Jt) acc[Tri<T>::idx(K, Jt)] = mfma4_new(Wk, acc[Tri<T>::idx(K, Jt)]);   // U_KJ = U_KK^-T M_KJ
@@ -902,7 +910,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   auto hx_full = [&](const double* XV) __attribute__((always_inline)) {
     hx_tiles<T>(k, XV, HX);
     if (NB > 0) {
-      __syncthreads();
+      WAVE_SYNC();
       double xb[NBB], sb[NBB];
 #pragma unroll
       for (int e = 0; e < NB; ++e) { xb[e] = XV[nc + e]; sb[e] = 0.0; }
@@ -948,7 +956,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   }
   const double cnt = fmax(1.0, wave_sum((double)cnt_local));
   infeas = wave_max((double)infeas) > 0;
-  __syncthreads();
+  WAVE_SYNC();
 
   STAMP_DECL
   int flag = 1, it = 0, flag_polished = 0;
@@ -975,12 +983,12 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     aZU[ix] = hu ? Z0 : 0.0;
     aW3[ix] = (js < J) ? ((hl ? Z0 : 0.0) - (hu ? Z0 : 0.0)) : 0.0;
   }
-  __syncthreads();
+  WAVE_SYNC();
   // bound multipliers absorb the initial dual residual r = Hx + g - A'(zl - zu)
   {
     hx_full(X);
     pass_Atw<T, NB>(k, aW3, P3);
-    __syncthreads();
+    WAVE_SYNC();
     for (int jb = 0; jb < k.JB; ++jb) {
       const int i = jb * 64 + lane, ix = (J + jb) * 64 + lane;
       if (i < n) {
@@ -989,7 +997,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         if (aU[ix] < INFINITY) aZU[ix] = fmax(-r, 0.0) + Z0;
       }
     }
-    __syncthreads();
+    WAVE_SYNC();
   }
 
   // fall-back iterate (best one that met tol_loose)
@@ -1052,7 +1060,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         for (int f = e + 1; f < NB; ++f) tt -= Ubb[e][f] * xb[f];
         xb[e] = tt / Ubb[e][e];
       }
-      __syncthreads();
+      WAVE_SYNC();
       for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
         if (i < nc) {
@@ -1066,7 +1074,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #pragma unroll
         for (int e = 0; e < NB; ++e) R[nc + e] = xb[e];
       }
-      __syncthreads();
+      WAVE_SYNC();
     }
   };
   // M = (acc from pass 1) + diag(aD on the variable rows), border columns = H~ border + A'DA border (MB); factorise in
@@ -1098,7 +1106,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       }
     }
     const double dmax = wave_max(dmax_l);
-    __syncthreads();
+    WAVE_SYNC();
     if (P.dump && b == 0 && P.dump_stage == 1 && it_now == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
 #pragma unroll
       for (int I = 0; I < T; ++I)
@@ -1121,7 +1129,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     if (NB > 0) {   // bordered factor: u_e = U^-T m_e came out of the forward sweep; S = M_bb - u'u is factorised as scalars
       double* vout[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
       rhs_store<T, 2 + NB>(k, rh, vout);
-      __syncthreads();
+      WAVE_SYNC();
       double S[NBB][NBB];
 #pragma unroll
       for (int e = 0; e < NB; ++e)
@@ -1155,7 +1163,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }
     reg_backward<T>(k, acc, YL, rh, SCR);
     { double* vout[2] = {R1, R2}; rhs_store<T, 2>(k, rh, vout); }
-    __syncthreads();
+    WAVE_SYNC();
     return 0;
   };
   // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place)
@@ -1165,7 +1173,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     reg_forward<T>(k, acc, YL, rh);
     if (NB > 0) {
       rhs_store<T, 1>(k, rh, vout);
-      __syncthreads();
+      WAVE_SYNC();
       border_solve(V);
       rhs_load<T, 1>(k, rh, vin);
     }
@@ -1184,7 +1192,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       }
       gap = wave_sum(s_gap);
       rp_rel = wave_max(m_rp);
-      __syncthreads();
+      WAVE_SYNC();
     }
     const double mu = gap / cnt;
 
@@ -1194,7 +1202,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     STAMP(2);
     acc_init<T>(k, acc);
     pass_syrk<T, NB>(k, acc, P1, P2, P3, MB);
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(3);
     // objective, dual residual
     double fl = 0, m_rd = 0;
@@ -1326,7 +1334,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     // the second-order term is dropped when the affine step is tiny (it then models nothing and makes the iteration
     // cycle on low-speed instances); this also saves the corrector solve and pass 3 for that iteration
     const double cw = a_aff >= 0.05 ? 1.0 : 0.0;
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(8);
     if (cw != 0.0) {
     // ================= corrector: P1 = A' w_cor came out of the fused pass 2 =================
@@ -1335,9 +1343,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const int i = lane + 64 * h;
       if (i < k.np) { const int ix = (J + (i >> 6)) * 64 + (i & 63); DX[i] = i < n ? P1[i] + aW1[ix] : 0.0; }
     }
-    __syncthreads();
+    WAVE_SYNC();
     solve1(DX);
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(10);
     // ================= pass 4: G dx_cor =================
     {
@@ -1349,7 +1357,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     } else {   // no corrector this iteration
       for (int i = lane; i < k.np; i += 64) DX[i] = 0.0;
       for (int js = 0; js < JT; ++js) aW2[js * 64 + lane] = 0.0;
-      __syncthreads();
+      WAVE_SYNC();
     }
     // full direction dx = dxa + smu*dxc + dxcor ; dv likewise
     for (int h = 0; h < 2; ++h) {
@@ -1435,7 +1443,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     gap = wave_sum(s_gap);
     rp_rel = wave_max(m_rp);
     xn = wave_max(xn); zn = wave_max(zn);
-    __syncthreads();
+    WAVE_SYNC();
     STAMP(12);
     // divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47)
     if (xn > 1e13) { flag = -3; break; }
@@ -1451,7 +1459,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     for (int i = lane; i < k.np; i += 64) X[i] = XS[i];
     for (int js = 0; js < JT; ++js) aW3[js * 64 + lane] = LAMS[js * 64 + lane];
     flag = 0;
-    __syncthreads();
+    WAVE_SYNC();
   } else if (flag == 0 || flag == 1) {
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
@@ -1459,7 +1467,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const bool hl = valid && aL[ix] > -INFINITY, hu = valid && aU[ix] < INFINITY;
       aW3[ix] = (hl ? aZL[ix] : 0.0) - (hu ? aZU[ix] : 0.0);
     }
-    __syncthreads();
+    WAVE_SYNC();
   }
   // ---- polish: from the interior-point point to the vertex an active-set solver (qpOASES) stops at ----
   // Active set W from the multipliers (side active iff |lambda| exceeds its slack), then the method of multipliers on
@@ -1486,16 +1494,16 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       PS[ix] = lo ? 1.0 : (up ? -1.0 : 0.0);
       aD[ix] = PA[ix]; aW1[ix] = 0.0; aW2[ix] = 0.0;
     }
-    __syncthreads();
+    WAVE_SYNC();
     acc_init<T>(k, acc);
     pass_syrk<T, NB>(k, acc, P1, P2, P3, MB);
-    __syncthreads();
+    WAVE_SYNC();
     for (int i = lane; i < k.np; i += 64) { R1[i] = 0.0; R2[i] = 0.0; }
-    __syncthreads();
+    WAVE_SYNC();
     bool pok = factor_solve2(-1) == 0;
     if (!pok) flag_polished = -5;
     for (int i = lane; i < k.np; i += 64) R2[i] = X[i];   // R2 = polished iterate
-    __syncthreads();
+    WAVE_SYNC();
     for (int pit = 0; pok; ++pit) {
       {
         const double* vin[1] = {R2}; double* rout[2] = {aVA, aVC};
@@ -1507,7 +1515,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         aVA[ix] = v; aVC[ix] = PY[ix] - PA[ix] * (v - PB[ix]);
       }
       hx_full(R2);
-      __syncthreads();
+      WAVE_SYNC();
       double m_rd = 0, m_rp = 0, m_sg = 0, m_cp = 0, fl2 = 0;
       for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
@@ -1557,15 +1565,15 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
           flag_polished = 1 + pit;
           fval_s = f2;
         }
-        __syncthreads();
+        WAVE_SYNC();
         break;
       }
-      __syncthreads();
+      WAVE_SYNC();
       solve1(DX);
-      __syncthreads();
+      WAVE_SYNC();
       for (int i = lane; i < k.np; i += 64) R2[i] += DX[i];
       for (int js = 0; js < JT; ++js) PY[js * 64 + lane] = aVC[js * 64 + lane];
-      __syncthreads();
+      WAVE_SYNC();
     }
   }
   const bool have_x = flag == 0 || flag == 1;
@@ -1583,9 +1591,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }
   }
   if (have_x && !v_current) {  // objective at the restored point, in the caller's units (H~,g~ scaling is objective preserving)
-    __syncthreads();
+    WAVE_SYNC();
     hx_full(X);
-    __syncthreads();
+    WAVE_SYNC();
     double fl = 0;
     for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < n) fl += 0.5 * X[i] * HX[i] + G[i] * X[i]; }
     fval_s = wave_sum(fl);
