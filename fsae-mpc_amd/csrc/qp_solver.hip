@@ -1404,6 +1404,19 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const double a_h = (-bp + mufull / (bd + amax_w * bdd)) / bdp;
       alpha = fmin(1.0, fmin(0.99999999 * amax_w, fmax(a_h, gamma_f * amax_w)));
     }
+#ifndef QP_NO_DBG4
+    if (P.dump && b == 0 && P.dump_stage == 4 && it == P.dump_iter) {   // debug: step-length pipeline of this iteration
+      double c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+      for (int js = 0; js < JT; ++js) { const int ix = js * 64 + lane; c1 += aVA[ix]; c2 += aVC[ix]; c3 += aW2[ix]; c4 += aW1[ix]; }
+      c1 = wave_sum(c1); c2 = wave_sum(c2); c3 = wave_sum(c3); c4 = wave_sum(c4);
+      if (lane == 0) {
+        double* o_ = P.dump;
+        o_[0] = a_aff; o_[1] = mu_aff; o_[2] = sigma; o_[3] = smu; o_[4] = cw; o_[5] = amax_w; o_[6] = alpha; o_[7] = gap; o_[8] = mu;
+        o_[9] = c1; o_[10] = c2; o_[11] = c3; o_[12] = c4; o_[13] = s1; o_[14] = s2; o_[15] = q1; o_[16] = q2;
+      }
+      for (int i = lane; i < n; i += 64) { P.dump[32 + i] = DX[i]; P.dump[32 + n + i] = R1[i]; P.dump[32 + 2 * n + i] = R2[i]; P.dump[32 + 3 * n + i] = P1[i]; }
+    }
+#endif
     // update, fused with the residual / weight phase of the next iteration
     double xn = 0, zn = 0, s_gap = 0, m_rp = 0;
     auto row3b_body = [&](const Slot& r, int js) {
