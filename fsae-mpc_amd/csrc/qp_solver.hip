@@ -1268,7 +1268,13 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       }
     }
     STAMP(4);
-    if (factor_solve2(it)) { flag = (res_ok || have_saved) ? 2 : -1; break; }
+    if (factor_solve2(it)) {
+      flag = (res_ok || have_saved) ? 2 : -1;
+      // the factorisation broke down (weights ~1e24) on an iterate that is primal feasible and complementary to tol_loose;
+      // only the dual residual is numerical noise: let the polish certify it (flag 4 -> 0 if accepted, else -1)
+      if (flag == -1 && P.polish && rp_rel <= P.tol_loose && gap_rel <= P.tol_loose) flag = 4;
+      break;
+    }
     STAMP(6);
     if (P.dump && b == 0 && P.dump_stage == 2 && it == P.dump_iter) {
       for (int i = lane; i < n; i += 64) { P.dump[i] = R1[i]; P.dump[n + i] = R2[i]; }
@@ -1467,13 +1473,13 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   }
 
   // ---- outputs ----
-  const bool v_current = flag == 0;   // aV still equals G x and fval_s is the objective at x (not so after a restore)
+  const bool v_current = flag == 0 || flag == 4;   // aV still equals G x and fval_s is the objective at x (not so after a restore)
   if (flag == 2) {  // restore the best iterate that met tol_loose
     for (int i = lane; i < k.np; i += 64) X[i] = XS[i];
     for (int js = 0; js < JT; ++js) aW3[js * 64 + lane] = LAMS[js * 64 + lane];
     flag = 0;
     WAVE_SYNC();
-  } else if (flag == 0 || flag == 1) {
+  } else if (flag == 0 || flag == 1 || flag == 4) {
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
       const bool valid = row_valid(k, js);
@@ -1489,7 +1495,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   // (residuals come from a fresh stream over A each time, so the ill-conditioned solve only has to contract).  It
   // reuses pass 1 (D = rho on W), the register factorisation and the fused pass-2 shape.  The result is accepted only
   // if it is a KKT point of the full QP to round-off level; otherwise the interior-point iterate is returned.
-  if (flag == 0 && P.polish) {
+  if ((flag == 0 || flag == 4) && P.polish) {
     const double rho = 1e6;
     double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
     if (!v_current) {
@@ -1564,7 +1570,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const double f2 = wave_sum(fl2);
       const bool conv = m_rd <= 1e-10 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2));
       if (P.dump && b < 32 && P.dump_stage == 3 && lane == 0) { double* o_ = P.dump + 64 * b + 8 * pit; o_[0] = m_rd; o_[1] = m_rp; o_[2] = m_sg; o_[3] = m_cp; o_[4] = conv; o_[5] = f2; }
-      if (conv || pit == 4) {
+      if (conv || pit == 7) {
         // accept only a true KKT point: multipliers of the right sign (round-off level wrong signs are zeroed)
         pok = conv && m_sg <= 1e-8;
         if (!pok) flag_polished = !(m_rd <= 1e-10) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!conv ? -3 : -4));
@@ -1577,6 +1583,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
           }
           flag_polished = 1 + pit;
           fval_s = f2;
+          flag = 0;
         }
         WAVE_SYNC();
         break;
@@ -1589,6 +1596,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       WAVE_SYNC();
     }
   }
+  if (flag == 4) flag = -1;   // not certified
   const bool have_x = flag == 0 || flag == 1;
   double* xo = P.x + (size_t)b * n;
   for (int i = lane; i < n; i += 64) xo[i] = have_x ? X[i] * EV[i] : NAN;

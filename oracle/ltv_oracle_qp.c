@@ -436,7 +436,11 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
     }
     double dmax = 0;
     for (int j = 0; j < n; ++j) dmax = fmax(dmax, M[IDX(j, j, n)]);
-    { int ce = chol_lower(n, M, 1e-30 * dmax); if (ce) { if (opts.verbose) printf("chol fail at %d dmax %g\n", ce, dmax); flag = res_ok ? 0 : (have_saved ? 2 : -1); break; } }
+    { int ce = chol_lower(n, M, 1e-30 * dmax); if (ce) { if (opts.verbose) printf("chol fail at %d dmax %g\n", ce, dmax); flag = res_ok ? 0 : (have_saved ? 2 : -1);
+        /* the factorisation broke down (weights ~1e24) on an iterate that is primal feasible and complementary to
+         * tol_loose; only the dual residual is numerical noise: let the active-set polish certify it (flag 4) */
+        if (flag == -1 && opts.polish && rp_rel <= opts.tol_loose && gap_rel <= opts.tol_loose) flag = 4;
+        break; } }
 
     /* predictor */
     for (int i = 0; i < mt; ++i)
@@ -549,23 +553,25 @@ finish:
     flag = 0;
   }
   /* unscale */
-  if (flag == 0 || flag == 1) {
+  if (flag == 0 || flag == 1 || flag == 4) {
     for (int j = 0; j < n; ++j) x_out[j] = x[j] * w.E[j];
     if (lambda_out) {
       for (int j = 0; j < n; ++j) lambda_out[j] = ((w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0)) / w.E[j];
       for (int r = 0; r < m; ++r) lambda_out[n + r] = ((w.hl[n + r] ? zl[n + r] : 0) - (w.hu[n + r] ? zu[n + r] : 0)) * w.F[r];
     }
-    if (flag == 0 && opts.polish) {
+    if ((flag == 0 || flag == 4) && opts.polish) {
       double* lam = lambda_out;
       if (!lam) {
         lam = (double*)malloc(sizeof(double) * mt);
         for (int j = 0; j < n; ++j) lam[j] = ((w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0)) / w.E[j];
         for (int r = 0; r < m; ++r) lam[n + r] = ((w.hl[n + r] ? zl[n + r] : 0) - (w.hu[n + r] ? zu[n + r] : 0)) * w.F[r];
       }
-      polish(n, m, H, g, A, lb, ub, lbA, ubA, opts.inf_bound, x_out, lam);
+      const int pol_ok = polish(n, m, H, g, A, lb, ub, lbA, ubA, opts.inf_bound, x_out, lam);
+      if (flag == 4) flag = pol_ok ? 0 : -1;
       if (!lambda_out) free(lam);
     }
-  } else {
+  }
+  if (!(flag == 0 || flag == 1)) {
     for (int j = 0; j < n; ++j) x_out[j] = NAN;
     if (lambda_out) for (int i = 0; i < mt; ++i) lambda_out[i] = NAN;
   }
