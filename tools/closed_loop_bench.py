@@ -33,11 +33,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--seed", type=int, default=20190)
+    ap.add_argument("--max-iter", type=int, default=100, help="interior-point iteration limit (bounds the batch tail)")
     a = ap.parse_args()
     model = fm.KINEMATIC if a.model == "kinematic" else fm.DYNAMIC
     tr = fm.Track.load("fss2019")
     cart0, s_init = initial_carts(tr, a.batch, a.seed)
-    cl = fm.ClosedLoop(model, a.horizon, 0.05, tr, cart0)
+    cl = fm.ClosedLoop(model, a.horizon, 0.05, tr, cart0, options=fm.default_opts(max_iter=a.max_iter))
     cl.x_opt[:, :, 0] += torch.from_numpy(s_init).cuda()[:, None]        # start the closest-point search near the car
     cl.x_opt[:, :, 3] += torch.from_numpy(cart0[:, 3]).cuda()[:, None]   # and the first linearisation at its speed
     flags_hist = {}
@@ -60,7 +61,7 @@ def main():
                                   "(frame transform + reference + linearise/condense/solve + PID/plant on the device; host loop with per-step flag readback)" % (a.batch, a.steps),
                       "exitflag_histogram": flags_hist, "mean_ipm_iterations": iters / (a.batch * a.steps),
                       "cars_lap_finished": int((cl.finished == 1).sum().item()), "cars_lost": int((cl.finished == 2).sum().item()), "mean_speed_end": float(cl.cart[:, 3].mean().item()),
-                      "median_abs_lateral_offset_end": float(np.nanmedian(np.abs(x0[:, 1]))), "seed": a.seed}}
+                      "median_abs_lateral_offset_end": float(np.nanmedian(np.abs(x0[:, 1]))), "seed": a.seed, "max_iter": a.max_iter}}
     print(json.dumps(res))
 
 
