@@ -11,7 +11,13 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/ref
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libfsaempc.so: $(LIBDIR)/qp_solver.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+# qp_solver.hip is compiled as five translation units (see the note in the file): main + four groups of tile counts
+QPOBJ := $(LIBDIR)/qp_solver_tu0.o $(LIBDIR)/qp_solver_tu1.o $(LIBDIR)/qp_solver_tu2.o $(LIBDIR)/qp_solver_tu3.o $(LIBDIR)/qp_solver_tu4.o
+$(LIBDIR)/qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DQP_TU=$* -c $< -o $@
+
+$(LIBDIR)/libfsaempc.so: $(QPOBJ) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # diagnostic build with in-kernel phase stamps (never benchmarked; see tools/phase_profile.py)

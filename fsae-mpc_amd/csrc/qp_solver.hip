@@ -94,6 +94,17 @@ template <int T> struct Tri {
   __host__ __device__ static constexpr int idx(int I, int J) { return I * T - (I * (I - 1)) / 2 + (J - I); }
 };
 
+// Translation units: the solve kernel is instantiated for T = 1..8 and three border widths; compiled in one piece
+// that is four minutes of hipcc, so the Makefile builds this file five times (-DQP_TU=0: prep kernel, dimensions,
+// dispatch, self test; -DQP_TU=1..4: one group of T each).  Without QP_TU everything lands in one object (used by the
+// one-command diagnostic builds).
+#if !defined(QP_TU) || QP_TU == 0
+#define QP_MAIN_TU 1
+#else
+#define QP_MAIN_TU 0
+#endif
+
+#if QP_MAIN_TU
 // ---------------------------------------------------------------------------------------------
 // qp_prep_kernel: scaling (E columns, F rows), repack of A and H, scaled g / bounds.  One wave per QP.
 // ---------------------------------------------------------------------------------------------
@@ -264,6 +275,8 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     Hb[e] = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
   }
 }
+
+#endif  // QP_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------
 // solve kernel
@@ -1657,6 +1670,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 // ---------------------------------------------------------------------------------------------
 // MFMA layout self test
 // ---------------------------------------------------------------------------------------------
+#if QP_MAIN_TU
 __global__ void mfma_selftest_kernel(const double* Am, const double* Bm, double* Cm) {
   // Am: 16x4 row-major (A[i][k]), Bm: 4x16 row-major (B[k][j]), Cm: 16x16 row-major out
   const int lane = threadIdx.x;
@@ -1667,8 +1681,11 @@ __global__ void mfma_selftest_kernel(const double* Am, const double* Bm, double*
 #pragma unroll
   for (int p = 0; p < 4; ++p) Cm[((lane >> 4) + 4 * p) * 16 + (lane & 15)] = c[p];
 }
+#endif  // QP_MAIN_TU
 
 }  // namespace
+
+#if QP_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -1815,6 +1832,8 @@ void qp_make_dims(int n, int m, QpDims* d) {
   }
 }
 
+#endif  // QP_MAIN_TU
+
 template <int T, int NB> static hipError_t launch_solve_TN(const QpParams& P, int batch, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_solve_kernel<T, NB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_solve);
@@ -1833,6 +1852,33 @@ template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, 
   }
 }
 
+#if defined(QP_TU)
+hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_launch_solve_g3(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st);
+#if QP_TU == 1
+hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st) {
+  switch (P.d.T) {
+    case 1: return launch_solve_T<1>(P, batch, st);
+    case 2: return launch_solve_T<2>(P, batch, st);
+    case 3: return launch_solve_T<3>(P, batch, st);
+    case 4: return launch_solve_T<4>(P, batch, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+#elif QP_TU == 2
+hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<5>(P, batch, st); }
+#elif QP_TU == 3
+hipError_t qp_launch_solve_g3(const QpParams& P, int batch, hipStream_t st) {
+  return P.d.T == 6 ? launch_solve_T<6>(P, batch, st) : launch_solve_TN<8, 0>(P, batch, st);
+}
+#elif QP_TU == 4
+hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<7>(P, batch, st); }
+#endif
+#endif
+
+#if QP_MAIN_TU
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_prep);
@@ -1853,6 +1899,7 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     return hipGetLastError();
   }
 #endif
+#if !defined(QP_TU)
   switch (P.d.T) {
 #ifdef QP_ONLY_T
     case QP_ONLY_T: return launch_solve_T<QP_ONLY_T>(P, batch, st);
@@ -1868,6 +1915,15 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
 #endif
     default: return hipErrorInvalidValue;
   }
+#else
+  switch (P.d.T) {
+    case 1: case 2: case 3: case 4: return qp_launch_solve_g1(P, batch, st);
+    case 5: return qp_launch_solve_g2(P, batch, st);
+    case 6: case 8: return qp_launch_solve_g3(P, batch, st);
+    case 7: return qp_launch_solve_g4(P, batch, st);
+    default: return hipErrorInvalidValue;
+  }
+#endif
 }
 
 int qp_selftest_mfma(char* msg, int msglen) {
@@ -1892,3 +1948,4 @@ int qp_selftest_mfma(char* msg, int msglen) {
   for (int i = 0; i < 256; ++i) if (hC[i] != ref[i]) { if (!bad) snprintf(msg, msglen, "mfma layout mismatch at (%d,%d): got %g want %g", i / 16, i % 16, hC[i], ref[i]); ++bad; }
   return bad;
 }
+#endif  // QP_MAIN_TU

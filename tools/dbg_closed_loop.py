@@ -42,3 +42,13 @@ for b in sel:
     print("car", b, "gpu flag", fl[b], "oracle flag", flo, "oracle iters", ito)
     agree += int((flo != 0) == (fl[b] != 0))
 print("agreement on solvable/unsolvable:", agree, "of", len(sel))
+
+# save a few failing QPs for offline inspection with the oracle's verbose trace
+import os
+os.makedirs("gpurun_out", exist_ok=True)
+keep = {}
+for b in sel[:6]:
+    for k_ in ("H", "g", "A", "lb", "ub", "lbA", "ubA"):
+        keep["%s_%d" % (k_, b)] = q[k_][b].cpu().numpy()
+keep["cars"] = np.array(sel[:6]); keep["flags"] = fl[sel[:6]]
+np.savez_compressed("gpurun_out/failing_qps.npz", **keep)
