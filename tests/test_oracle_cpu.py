@@ -288,3 +288,29 @@ def test_cl_pre_matches_its_parts(orc, otrack, model):
     assert x0[3] == (np.hypot(12.0, 0.7) if model == 0 else 12.0) and x0[-1] == -0.03
     assert np.array_equal(x_ref, orc.reference_live(x0.size, 40, 0.05, x0))      # x(4) < TARGET_VEL here, same ramp
     assert orc.cl_pre(model, 40, 0.05, otrack, cart, 32.5 + otrack.L)[2] == 1      # a lap further: finished
+
+
+@pytest.mark.parametrize("name", ["fsg2019", "fss2019", "fso2020"])
+def test_track_tables_are_periodic_arclength_splines(name):
+    """The committed spline tables (tools/make_track_tables.py: read_raceline_csv -> make_spline_periodic -> arclength_reparam,
+    SURVEY 8 f-2) are closed C2 cubic Bezier chains, approximately uniformly spaced in arc length."""
+    import json, os
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "..", "fsae-mpc_amd", "tracks", name + ".json")))
+    M, dl, L = len(d["xP"]), d["dl"], d["L"]
+    assert M == 100 and abs(M * dl - L) < 1e-9 * L                                    # main.m:17 (100 segments)
+    for P in (np.array(d["xP"]), np.array(d["yP"])):
+        nxt = np.roll(P, -1, axis=0)
+        assert np.allclose(P[:, 3], nxt[:, 0], atol=1e-9)                            # C0, closed
+        assert np.allclose(P[:, 3] - P[:, 2], nxt[:, 1] - nxt[:, 0], atol=1e-8)      # C1: make_spline_periodic.m:9-33
+        assert np.allclose(P[:, 3] - 2 * P[:, 2] + P[:, 1], nxt[:, 2] - 2 * nxt[:, 1] + nxt[:, 0], atol=1e-7)   # C2
+    # arc length: each segment is dl long (bisection tolerance 0.01 m, arclength_reparam.m:49), speed |dr/ds| ~ 1
+    X, Y = np.array(d["xP"]), np.array(d["yP"])
+    u = np.linspace(0, 1, 201)[None, :]
+    def der(P):
+        return (-3 * (1 - u) ** 2 * P[:, :1] + 3 * (3 * u * u - 4 * u + 1) * P[:, 1:2] + 3 * (2 * u - 3 * u * u) * P[:, 2:3] + 3 * u * u * P[:, 3:4])
+    speed = np.hypot(der(X), der(Y))                                                   # per unit of the segment parameter
+    seg_len = ((speed[:, 1:] + speed[:, :-1]) * 0.5 * (u[0, 1] - u[0, 0])).sum(axis=1)
+    # the reference's segment-length quirk (arclength_reparam.m:20-23 uses x_P(i,1) for x_P(i,2)) is reproduced, so the
+    # re-parametrisation is only approximately uniform: segments within 25 % of dl, total length within 5 % of L
+    assert np.max(np.abs(seg_len / dl - 1)) < 0.25 and abs(seg_len.sum() / L - 1) < 0.05
+    assert np.max(np.abs(speed / dl - 1)) < 0.35
