@@ -5,7 +5,7 @@ CSRC    := fsae-mpc_amd/csrc
 LIBDIR  := fsae-mpc_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-all: $(LIBDIR)/libfsaempc.so oracle
+all: $(LIBDIR)/libfsaempc.so oracle o1
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h $(CSRC)/plant.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
@@ -26,10 +26,17 @@ $(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CS
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
 
+# guard build: the same sources at -O1 (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build compares the two on the
+# GPU; see DESIGN.md "Known fragility").  Only T = 5 and T = 8 kernels (the headline shape and the spill-heavy one).
+o1: $(LIBDIR)/libfsaempc_O1.so
+$(LIBDIR)/libfsaempc_O1.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -O1 -std=c++17 -fPIC -Iinclude -I$(CSRC) -DQP_O1_GUARD=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
 	rm -rf $(LIBDIR)/*.o $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean stamps
+.PHONY: all oracle clean stamps o1

@@ -1901,7 +1901,10 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
 #endif
 #if !defined(QP_TU)
   switch (P.d.T) {
-#ifdef QP_ONLY_T
+#if defined(QP_O1_GUARD)
+    case 5: return launch_solve_T<5>(P, batch, st);
+    case 8: return launch_solve_TN<8, 0>(P, batch, st);
+#elif defined(QP_ONLY_T)
     case QP_ONLY_T: return launch_solve_T<QP_ONLY_T>(P, batch, st);
 #else
     case 1: return launch_solve_T<1>(P, batch, st);

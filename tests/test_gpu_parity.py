@@ -462,3 +462,31 @@ def test_sqp_sweeps(fm, torch_, orc, model):
         checked += 1
         assert np.max(np.abs(out["u_opt"][b].cpu().numpy() - u)) <= 1e-3 * max(1.0, np.abs(u).max()), b
     assert checked >= B // 2
+
+
+def test_shipped_build_matches_O1_build(fm, tmp_path):
+    """Guard against schedule-dependent miscompiles of the big solve kernel ("Known fragility"): the shipped -O3
+    library and an -O1 build of the same sources (make o1) must walk the same iterates -- same exit flags, iteration counts
+    within a few steps, x within the solve tolerance -- on the headline shape, the 4-column-border shape and the
+    spill-heavy T = 8 shape.  Each library runs in its own process (the library handle is process-wide)."""
+    import os, subprocess, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    o1 = os.path.join(root, "fsae-mpc_amd", "lib", "libfsaempc_O1.so")
+    if not os.path.exists(o1):
+        pytest.skip("guard library not built (make o1)")
+    res = {}
+    for tag, lib in (("O3", None), ("O1", o1)):
+        env = dict(os.environ)
+        env.pop("FSAEMPC_LIB", None)
+        if lib:
+            env["FSAEMPC_LIB"] = lib
+        out = str(tmp_path / ("optcmp_%s.npz" % tag))
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "dbg_opt_compare.py"), tag, out], env=env, cwd=root,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        res[tag] = np.load(out)
+    for k in ("kin40", "dyn40", "dyn60"):
+        a, b = res["O1"], res["O3"]
+        assert (a[k + "_fl"] == 0).all() and (b[k + "_fl"] == 0).all(), k
+        assert np.abs(a[k + "_it"].astype(int) - b[k + "_it"].astype(int)).max() <= 4, k
+        assert abs(int(a[k + "_it"].sum()) - int(b[k + "_it"].sum())) <= 0.02 * int(b[k + "_it"].sum()), k
+        assert np.abs(a[k + "_x"] - b[k + "_x"]).max() <= 1e-5 * max(1.0, np.abs(b[k + "_x"]).max()), k
