@@ -172,7 +172,8 @@ def main():
             res["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
         res["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side, PMC, see profiles/round1/pmc_traffic_kinN40_B4096.json)"
 
-    if rank == 0 and not args.no_cpu_baseline:
+    res["cpu_baseline"] = None    # timed on rank 0 at N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as orc
         otr = orc.Track.load(os.path.join(ROOT, "fsae-mpc_amd", "tracks", "fsg2019.json"))
         cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
