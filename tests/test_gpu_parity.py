@@ -490,3 +490,22 @@ def test_shipped_build_matches_O1_build(fm, tmp_path):
         assert np.abs(a[k + "_it"].astype(int) - b[k + "_it"].astype(int)).max() <= 4, k
         assert abs(int(a[k + "_it"].sum()) - int(b[k + "_it"].sum())) <= 0.02 * int(b[k + "_it"].sum()), k
         assert np.abs(a[k + "_x"] - b[k + "_x"]).max() <= 1e-5 * max(1.0, np.abs(b[k + "_x"]).max()), k
+
+
+@pytest.mark.parametrize("model,N", [(0, 24), (0, 28), (0, 31), (0, 48), (0, 56), (1, 22), (1, 30), (1, 46), (1, 54)])
+def test_every_tile_count_instantiation(fm, torch_, orc, model, N):
+    """One horizon per kernel instantiation not reached by the BASELINE shapes: T = 3, 4, 6, 7 with border widths 0, 1
+    and 4 (nV = 2N+1 / 2N+4) -- solve parity with the oracle through the generic entry point."""
+    torch = torch_
+    B = 12
+    otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, otr.L, 404, range(B))
+    q = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul)
+    out = _solve_dev(fm, torch, q)
+    xo, fo, flo, ito, lamo, _ = orc.qp_solve_batch(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"])
+    ok = flo == 0
+    assert ok.sum() >= B - 2 and (out["exitflag"][ok] == 0).all(), (flo, out["exitflag"])
+    for b in np.nonzero(ok)[0]:
+        kkt = orc.qp_kkt(q["H"][b].T, q["g"][b], q["A"][b].T, q["lb"][b], q["ub"][b], q["lbA"][b], q["ubA"][b], out["x"][b], out["lam"][b])[0]
+        assert kkt <= KKT_TOL, (b, kkt)
+        assert abs(out["fval"][b] - fo[b]) <= FVAL_TOL * max(1.0, abs(fo[b])), b
