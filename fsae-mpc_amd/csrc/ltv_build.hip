@@ -262,7 +262,13 @@ template <int NX> __global__ __launch_bounds__(256) void ltv_build_kernel(LtvPar
   double* cc = aff + R;                  // per-step constraint coefficient scratch: N * CW
   constexpr int CW = (NX == 5) ? 3 : (2 * 4 + 2 + 4 + 2);  // kin: C3,C4,const ; dyn: slip rows (2x4 coef + 2 const), tyre (4 coef K-part) + 2
   double* red = cc + (size_t)N * CW;     // reduction scratch (nth)
+  double* ell = red + nth;               // 24: dac[12], dal[12] of the inscribed 12-gon (dynamic_tyre_linearise_constraints.m:33-39)
 
+  if (tid < 12) {
+    const int j = tid;
+    const double th0 = 2 * M_PI * (double)j / 12, th1 = (j + 1 == 12) ? 2 * M_PI : 2 * M_PI * (double)(j + 1) / 12;
+    ell[j] = 9.163 * sin(th1) - 9.163 * sin(th0); ell[12 + j] = 10.0 * cos(th1) - 10.0 * cos(th0);
+  }
   // ---- 1. linearise every step (one thread per step) ----
   for (int k = tid; k < N; k += nth)
     linearise_step<NX>(x_lin + (size_t)k * NX, u_lin + (size_t)k * 2, sp, dt, P.integ, Ad + (size_t)k * NN, Bd + (size_t)k * NX * 2, dd + (size_t)k * NX);
@@ -363,8 +369,11 @@ template <int NX> __global__ __launch_bounds__(256) void ltv_build_kernel(LtvPar
     }
   }
   // ---- 4c. constraint matrix A (nC x nV, column-major); threads sweep rows fastest for coalesced stores ----
-  for (size_t e = tid; e < (size_t)nC * nV; e += nth) {
-    const int row = (int)(e % nC), col = (int)(e / nC);
+  // (row, col) advance incrementally with e (no integer division per entry); the 12 half-plane directions of the tyre
+  // ellipse come from a small LDS table instead of sin/cos per entry
+  int row = tid % nC, col = tid / nC;
+  for (int e = tid; e < nC * nV; e += nth, row += nth) {
+    while (row >= nC) { row -= nC; ++col; }
     const double* bcol = Bt + (size_t)col * R;
     double v = 0.0;
     if (row < 4 * N) {
@@ -386,8 +395,7 @@ template <int NX> __global__ __launch_bounds__(256) void ltv_build_kernel(LtvPar
     } else {
       const int rr = row - 8 * N, k = rr / 12, j = rr - 12 * k;
       const double* ck = cc + (size_t)k * CW;
-      const double th0 = 2 * M_PI * (double)j / 12, th1 = (j + 1 == 12) ? 2 * M_PI : 2 * M_PI * (double)(j + 1) / 12;
-      const double dac = 9.163 * sin(th1) - 9.163 * sin(th0), dal = 10.0 * cos(th1) - 10.0 * cos(th0);
+      const double dac = ell[j], dal = ell[12 + j];
       for (int jj = 0; jj < 3; ++jj) v += dal * ck[10 + jj] * bcol[k * NX + 3 + jj];
       if (col == 2 * k) v += dac;
       if (col == scol + 3) v = -1.0;
@@ -466,7 +474,7 @@ __global__ void ltv_post_kernel(int nx, int N, int ns, const double* z, const do
 
 size_t ltv_build_lds_bytes(int nx, int N, int threads) {
   const int CW = (nx == 5) ? 3 : 16;
-  return ((size_t)N * nx * nx + (size_t)N * nx * 2 + (size_t)N * nx + (size_t)nx * N + (size_t)N * CW + threads) * sizeof(double);
+  return ((size_t)N * nx * nx + (size_t)N * nx * 2 + (size_t)N * nx + (size_t)nx * N + (size_t)N * CW + threads + 24) * sizeof(double);
 }
 
 hipError_t ltv_build_launch(const LtvParams& P, int batch, hipStream_t st) {
