@@ -17,14 +17,20 @@ $(LIBDIR)/qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsa
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_TU=$* -c $< -o $@
 
-$(LIBDIR)/libfsaempc.so: $(QPOBJ) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+# qp_wg.hip (workgroup-per-QP solve kernel) is compiled once per range of tile counts T (lo:hi)
+WGOBJ := $(LIBDIR)/qp_wg_1_4.o $(LIBDIR)/qp_wg_5_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_7_8.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
+$(LIBDIR)/qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*)) -c $< -o $@
+
+$(LIBDIR)/libfsaempc.so: $(QPOBJ) $(WGOBJ) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # diagnostic build with in-kernel phase stamps (never benchmarked; see tools/phase_profile.py)
 stamps: $(LIBDIR)/libfsaempc_stamps.so
-$(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
+$(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/qp_wg.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
+	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -DQP_ONLY_T=5 -DQP_WG_ONE_TU -DQP_WG_TLO=5 -DQP_WG_THI=5 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/qp_wg.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
 
 # guard build: the same sources at -O1 (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build compares the two on the
 # GPU; see DESIGN.md "Known fragility").  Only T = 5 and T = 8 kernels (the headline shape and the spill-heavy one).

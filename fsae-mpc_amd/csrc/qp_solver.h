@@ -14,6 +14,9 @@ struct QpDims {
   int rowlen;      // (J+JB)*64
   size_t off_Aw, off_meta, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, ws_per_qp;  // in doubles
   size_t lds_solve, lds_prep;                                                  // in bytes
+  int W;                  // wavefronts per QP of the workgroup solve kernel (qp_wg.hip): 4, or 8 when one workgroup fills a CU
+  size_t lds_aw_bytes;    // LDS reserved for the resident operand stream (0: the passes read it from global memory)
+  size_t lds_wg;          // total dynamic LDS of the workgroup solve kernel
 };
 
 struct QpParams {
@@ -24,6 +27,7 @@ struct QpParams {
   int *exitflag, *iter;
   double tol, tol_loose, tol_x, inf_bound;
   int max_iter, shared_HA, polish;
+  int only_pending;   // workgroup kernel, streaming variant: solve only the instances the resident variant handed over (exit flag QP_FLAG_PENDING)
   int* polished;   // optional per-instance output: 1 if the active-set polish was accepted
   double* dump; int dump_stage, dump_iter;
 };
@@ -31,3 +35,12 @@ struct QpParams {
 void qp_make_dims(int n, int m, QpDims* d);
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid = nullptr);
 int qp_selftest_mfma(char* msg, int msglen);
+// LDS bytes of the workgroup solve kernel (qp_wg.hip) without the resident operand stream: n-vectors + 4 border columns,
+// U_KK^-T tiles, panel-row tiles, 2 x W partial n-vectors, reduction scratch
+#define QP_WG_NVEC 10
+inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W) {
+  return ((size_t)(QP_WG_NVEC + 4) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + (size_t)2 * W * d.np + (size_t)2 * 8 * W) * sizeof(double);
+}
+#define QP_MAX_T 12
+#define QP_WG_RES_MAX_T 6      // tile counts for which the LDS-resident variant is built
+#define QP_FLAG_PENDING 99

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "qp_solver.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -1810,6 +1811,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->ntr = (d->Kq + 3) / 4;   // trips of 4 k-steps (16 rows)
   d->off_Aw = off; off += (size_t)(2 * d->ntr) * d->T * 128;   // dense upper bound of the operand stream
   d->off_meta = off; off += ((size_t)(d->J > 0 ? d->J : 1) * 64 + 2 * (size_t)d->ntr + 1 + 16 + 1) / 2 + 1;   // int arrays: perm, tcs, aoff, tend
+  off = (off + 1) & ~(size_t)1;   // keep every array 16-byte aligned (pairs of k-steps are read as 16-byte lane loads)
   d->off_Hw = off; off += (size_t)d->T * d->T * 4 * 64;
   d->off_gw = off; off += d->np;
   d->off_E = off; off += d->np;
@@ -1823,6 +1825,25 @@ void qp_make_dims(int n, int m, QpDims* d) {
   {
     const int Tt = d->T, Dd = Tt <= 5 ? 6 : (Tt == 6 ? 4 : (Tt == 7 ? 3 : 2));   // = StreamCfg<T>::D
     d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272 + (size_t)(Dd + Tt) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);
+  }
+  {   // workgroup solve kernel (qp_wg.hip): keep the operand stream of A~ resident in LDS when ~2/3 of its dense size fits
+      // (structurally empty tiles are skipped, the LTV-MPC families keep ~60 %); a QP whose stream turns out larger
+      // falls back to reading it from global memory inside the kernel
+    const size_t cap = 160 * 1024 - 2048;
+    const size_t dense = (size_t)2 * d->ntr * d->T * 1024;
+    d->W = 4; d->lds_aw_bytes = 0;
+    for (int Wt = 4; Wt <= 8; Wt += 4) {
+      const size_t base = qp_wg_lds_base_bytes(*d, Wt);
+      if (base >= cap) break;
+      const size_t avail = (cap - base) & ~(size_t)1023;
+      if (dense * 2 / 3 <= avail && dense > 0) {
+        const size_t take = dense < avail ? dense : avail;
+        if (Wt == 4 && take + base > 80 * 1024) continue;   // one workgroup per CU anyway: use 8 wavefronts
+        d->W = Wt; d->lds_aw_bytes = take;
+        break;
+      }
+    }
+    d->lds_wg = qp_wg_lds_base_bytes(*d, d->W) + d->lds_aw_bytes;
   }
   d->prep_tw = 16;
   for (;;) {
@@ -1879,6 +1900,29 @@ hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st) { re
 #endif
 
 #if QP_MAIN_TU
+// qp_wg.hip is built as several translation units (one per range of tile counts, named by its first T); a one-command
+// build (-DQP_WG_ONE_TU) has everything in the unit named 1
+hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
+#ifndef QP_WG_ONE_TU
+hipError_t qp_wg_launch_5(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_6(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_7(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_9(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_11(const QpParams& P, int batch, hipStream_t st);
+#endif
+static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) {
+#ifdef QP_WG_ONE_TU
+  return qp_wg_launch_1(P, batch, st);
+#else
+  const int T = P.d.T;
+  if (T <= 4) return qp_wg_launch_1(P, batch, st);
+  if (T == 5) return qp_wg_launch_5(P, batch, st);
+  if (T == 6) return qp_wg_launch_6(P, batch, st);
+  if (T <= 8) return qp_wg_launch_7(P, batch, st);
+  if (T <= 10) return qp_wg_launch_9(P, batch, st);
+  return qp_wg_launch_11(P, batch, st);
+#endif
+}
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_prep);
@@ -1899,6 +1943,10 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     return hipGetLastError();
   }
 #endif
+  {   // round-2 workgroup-per-QP kernel (qp_wg.hip); FSAEMPC_QP_V1=1 selects the round-1 one-wavefront kernel (T <= 8) for A/B runs
+    static const bool use_v1 = getenv("FSAEMPC_QP_V1") != nullptr;
+    if (!use_v1 || P.d.T > 8) return qp_wg_launch(P, batch, st);
+  }
 #if !defined(QP_TU)
   switch (P.d.T) {
 #if defined(QP_O1_GUARD)

@@ -27,7 +27,7 @@ extern "C" {
 #define FSAEMPC_ERR_NODEVICE (-4)  /* no gfx950 device / code object not loadable: there is NO CPU fallback */
 #define FSAEMPC_ERR_WORKSPACE (-5) /* workspace too small */
 
-#define FSAEMPC_MAX_NV 128
+#define FSAEMPC_MAX_NV 196   /* 12 column tiles of 16 + up to 4 border columns (config 5: dynamic N = 80, nV = 164) */
 
 #define FSAEMPC_MODEL_KINEMATIC 0  /* mpc/ltv/kinematic/ltvmpc_kinetmatic_curvilinear.m */
 #define FSAEMPC_MODEL_DYNAMIC   1  /* mpc/ltv/dynamic/ltvmpc_dynamic_curvilinear.m */
