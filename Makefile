@@ -17,8 +17,8 @@ $(LIBDIR)/qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsa
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_TU=$* -c $< -o $@
 
-# qp_wg.hip (workgroup-per-QP solve kernel) is compiled once per range of tile counts T (lo:hi)
-WGOBJ := $(LIBDIR)/qp_wg_1_4.o $(LIBDIR)/qp_wg_5_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_7_8.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
+# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 9..12) is compiled once per range of tile counts (lo_hi)
+WGOBJ := $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
 $(LIBDIR)/qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*)) -c $< -o $@
@@ -31,6 +31,20 @@ stamps: $(LIBDIR)/libfsaempc_stamps.so
 $(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/qp_wg.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -DQP_ONLY_T=5 -DQP_WG_ONE_TU -DQP_WG_TLO=5 -DQP_WG_THI=5 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/qp_wg.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
+
+# development build: only T = 5 kernels (headline shapes), plain and with phase stamps; select with FSAEMPC_LIB
+DEVFLAGS := -DQP_ONLY_T=5 -DQP_WG_ONE_TU -DQP_WG_TLO=5 -DQP_WG_THI=5 -DQP_WG_DEV
+$(LIBDIR)/dev_%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEVFLAGS) -c $< -o $@
+$(LIBDIR)/devst_%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEVFLAGS) -DQP_STAMPS=1 -c $< -o $@
+devlib: $(LIBDIR)/libfsaempc_dev.so $(LIBDIR)/libfsaempc_devst.so
+$(LIBDIR)/libfsaempc_dev.so: $(LIBDIR)/dev_qp_solver.o $(LIBDIR)/dev_qp_wg.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+$(LIBDIR)/libfsaempc_devst.so: $(LIBDIR)/dev_qp_solver.o $(LIBDIR)/devst_qp_wg.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # guard build: the same sources at -O1 (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build compares the two on the
 # GPU; see DESIGN.md "Known fragility").  Only T = 5 and T = 8 kernels (the headline shape and the spill-heavy one).
@@ -45,4 +59,4 @@ oracle:
 clean:
 	rm -rf $(LIBDIR)/*.o $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean stamps o1
+.PHONY: all oracle clean stamps o1 devlib

@@ -56,7 +56,7 @@ int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc, const double* H, 
   QpParams P; memset(&P, 0, sizeof(P));
   qp_make_dims(desc->nV, desc->nC, &P.d);
   if ((long long)(P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
-  if (P.d.lds_wg > 160 * 1024 || P.d.lds_prep > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of this kernel generation");
+  if ((P.d.T > 8 ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024 || (P.d.T > 8 && P.d.J + P.d.JB > 32)) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels (nV > 128 supports up to ~1850 constraint rows)");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
   P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = g_polished;

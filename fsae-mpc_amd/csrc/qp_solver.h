@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#define QP_MAX_T 12
+#define QP_WG_RES_MAX_T 6      // tile counts for which the LDS-resident variant (and the 1-column border) is built
+#define QP_FLAG_PENDING 99
+
 struct QpDims {
   int n, m;        // variables, general rows
   int T, np;       // 16-wide column tiles of the MFMA core (nc = 16T columns), padded vector length
@@ -14,7 +18,8 @@ struct QpDims {
   int rowlen;      // (J+JB)*64
   size_t off_Aw, off_meta, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, ws_per_qp;  // in doubles
   size_t lds_solve, lds_prep;                                                  // in bytes
-  int W;                  // wavefronts per QP of the workgroup solve kernel (qp_wg.hip): 4, or 8 when one workgroup fills a CU
+  int W;                  // wavefronts per QP of the workgroup solve kernel (qp_wg.hip)
+  int NBk;                // border width of the kernel variant: 0, 1 (only nb == 1 and T <= QP_WG_RES_MAX_T) or 4
   size_t lds_aw_bytes;    // LDS reserved for the resident operand stream (0: the passes read it from global memory)
   size_t lds_wg;          // total dynamic LDS of the workgroup solve kernel
 };
@@ -35,12 +40,12 @@ struct QpParams {
 void qp_make_dims(int n, int m, QpDims* d);
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid = nullptr);
 int qp_selftest_mfma(char* msg, int msglen);
-// LDS bytes of the workgroup solve kernel (qp_wg.hip) without the resident operand stream: n-vectors + 4 border columns,
-// U_KK^-T tiles, panel-row tiles, 2 x W partial n-vectors, reduction scratch
-#define QP_WG_NVEC 10
-inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W) {
-  return ((size_t)(QP_WG_NVEC + 4) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + (size_t)2 * W * d.np + (size_t)2 * 8 * W) * sizeof(double);
+// LDS bytes of the workgroup solve kernel (qp_wg.hip) without the resident operand stream; NBk = border width of the
+// kernel variant (0, 1 or 4).  Mirrors the carve at the top of qp_wg_kernel.
+#define QP_WG_NVEC_FIXED 14   /* X G HX P1 P2 P3 DX E R1 R2 + DV W1V W2V LV */
+inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk, bool res) {
+  const size_t JS = (size_t)d.J * 64;
+  return ((size_t)(QP_WG_NVEC_FIXED + 2 * NBk) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + (size_t)W * 96 +
+          (size_t)2 * 8 * W + (6 + (res ? (size_t)NBk : 0)) * JS) * sizeof(double);
 }
-#define QP_MAX_T 12
-#define QP_WG_RES_MAX_T 6      // tile counts for which the LDS-resident variant is built
-#define QP_FLAG_PENDING 99
+

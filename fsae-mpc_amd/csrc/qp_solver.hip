@@ -27,6 +27,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include "qp_solver.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -529,14 +530,14 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
 //   w_r = (va+a1)(b1 + c1 (va+a1)) - (a2-va)(b2 + c2 (a2-va))      (a,b,c: per-row coefficients of row phase 1)
 // is formed and p_cor += w_r a_r is accumulated in the same pass (saves one full stream over A per iteration).
 // FUSE 3 is the polish step (see the kernel).  Same operand stream and phase structure as pass 1.
-template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor, double* Pcor2 = nullptr) {
+template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, const double* const* vin, double* const* rout, double* Pcor, double* Pcor2 = nullptr, const double* const* cfarr = nullptr) {
   constexpr int NBB = NB > 0 ? NB : 1;
   constexpr int NC = FUSE == 1 ? 6 : (FUSE >= 2 ? 3 : 0);   // per-row coefficient arrays of the fused part
   constexpr int NA = NC + NB;
   const int JS = k.J * 64;
   const double* arr[NA > 0 ? NA : 1];
   if (FUSE == 1) { arr[0] = rowp(k, R_RPL); arr[1] = rowp(k, R_CB1); arr[2] = rowp(k, R_CC1); arr[3] = rowp(k, R_RPU); arr[4] = rowp(k, R_CB2); arr[5] = rowp(k, R_CC2); }
-  if (FUSE >= 2) { arr[0] = rowp(k, R_CB1); arr[1] = rowp(k, R_RPL); arr[2] = rowp(k, R_CC1); }   // polish: rho*act, target b, multiplier y
+  if (FUSE >= 2) { arr[0] = cfarr ? cfarr[0] : rowp(k, R_CB1); arr[1] = cfarr ? cfarr[1] : rowp(k, R_RPL); arr[2] = cfarr ? cfarr[2] : rowp(k, R_CC1); }   // refinement: rho*act, target b, multiplier y
 #pragma unroll
   for (int f = 0; f < NB; ++f) arr[NC + f] = k.Ab + (size_t)f * JS;
   double v[NVEC][T], vb[NVEC][NBB], pc[T], pcb[NBB], pd[FUSE >= 2 ? T : 1], pdb[NBB];
@@ -1502,16 +1503,21 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }
     WAVE_SYNC();
   }
-  // ---- polish: from the interior-point point to the vertex an active-set solver (qpOASES) stops at ----
-  // Active set W from the multipliers (side active iff |lambda| exceeds its slack), then the method of multipliers on
-  //   min 1/2 x'H x + g'x  s.t. G_W x = b_W     with one Newton step per outer iteration, in correction form:
-  //   c = G_W x - b,  y <- y - rho c,  x <- x - (H + rho G_W'G_W)^-1 (H x + g - G_W' y + rho G_W' c)
-  // (residuals come from a fresh stream over A each time, so the ill-conditioned solve only has to contract).  It
-  // reuses pass 1 (D = rho on W), the register factorisation and the fused pass-2 shape.  The result is accepted only
-  // if it is a KKT point of the full QP to round-off level; otherwise the interior-point iterate is returned.
+  // ---- active-set refinement: from the interior-point point to the vertex an active-set solver (qpOASES) stops at ----
+  // Working set W from the multipliers (side active iff |lambda| exceeds its slack).  Active *bounds* are eliminated
+  // exactly: the variable is pinned (huge diagonal, zero right-hand side, value reset after every update) and its
+  // multiplier is read off the stationarity residual.  Active *rows* A_W z = b: conjugate gradients on the dual of the
+  // augmented problem, operator S = A_W M^-1 A_W' with M = H~ + pin + rho A_W'A_W (resident Cholesky factor).  Its
+  // spectrum is clustered at 1/rho plus a few small outliers from nearly dependent active rows (long stretches of the
+  // horizon on a track limit): CG removes the outliers in one step each, the fixed-step method of multipliers of round 1
+  // could not (rejected 10-20 % of the instances).  One fused stream over A~ per CG step (q = A_W w and A_W'q together),
+  // A'p kept by recurrence.  The result is accepted only if a fresh evaluation says it is a KKT point of the full QP;
+  // otherwise the interior-point iterate is returned.
   if ((flag == 0 || flag == 4) && P.polish) {
-    const double rho = 1e6;
+    const double rho = 1e6, pin = 1e16, rinv = 1.0 / rho;
     double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
+    double* PC = rowp(k, R_RPU); double* PP = rowp(k, R_CC2); double* PZ0 = aW2;   // constraint residual c, CG direction p, zeros
+    double* ATR = R1; double* ATP = P3;                                               // A_W'r and A_W'p (n-vectors, by recurrence)
     if (!v_current) {
       const double* vin[1] = {X}; double* rout[1] = {aV};
       pass_Av<T, NB, 1, 0>(k, vin, rout, nullptr);
@@ -1523,9 +1529,18 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const double l = aL[ix], u = aU[ix], v = aV[ix], lam = aW3[ix];
       const bool lo = valid && l > -INFINITY && lam > 0 && lam > fabs(v - l);
       const bool up = valid && u < INFINITY && lam < 0 && -lam > fabs(u - v);
-      PA[ix] = (lo || up) ? rho : 0.0; PB[ix] = lo ? l : (up ? u : 0.0); PY[ix] = (lo || up) ? lam : 0.0;
-      PS[ix] = lo ? 1.0 : (up ? -1.0 : 0.0);
-      aD[ix] = PA[ix]; aW1[ix] = 0.0; aW2[ix] = 0.0;
+      PS[ix] = lo ? 1.0 : (up ? -1.0 : 0.0); PY[ix] = ((lo || up) && js < J) ? lam : 0.0;
+    }
+    for (int i = lane; i < k.np; i += 64) XS[i] = X[i];   // z of the refinement between attempts (the fall-back copy is no longer needed)
+    WAVE_SYNC();
+    // up to three attempts: a refinement that ends on a violated inactive row / a multiplier of the wrong sign adds / drops
+    // that one row and starts over from the point it reached (single add-drop corrections of an active-set method)
+    for (int attempt = 0; attempt < 3 && flag_polished <= 0; ++attempt) {
+    for (int js = 0; js < JT; ++js) {
+      const int ix = js * 64 + lane;
+      const double sd = PS[ix];
+      PA[ix] = sd != 0.0 ? rho : 0.0; PB[ix] = sd > 0 ? aL[ix] : (sd < 0 ? aU[ix] : 0.0);
+      aD[ix] = js < J ? PA[ix] : (sd != 0.0 ? pin : 0.0); aW1[ix] = 0.0; aW2[ix] = 0.0; PC[ix] = 0.0; PP[ix] = 0.0;
     }
     WAVE_SYNC();
     acc_init<T>(k, acc);
@@ -1533,39 +1548,134 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     WAVE_SYNC();
     for (int i = lane; i < k.np; i += 64) { R1[i] = 0.0; R2[i] = 0.0; }
     WAVE_SYNC();
-    bool pok = factor_solve2(-1) == 0;
-    if (!pok) flag_polished = -5;
-    for (int i = lane; i < k.np; i += 64) R2[i] = X[i];   // R2 = polished iterate
+    bool pok = factor_solve2(-1) == 0, retry = false;
+    if (!pok) { flag_polished = -5; break; }
+    // z: the point reached so far (R1, R2 were the right-hand sides of the factorisation), pinned variables on their bounds
+    for (int h = 0; h < 2; ++h) {
+      const int i = lane + 64 * h;
+      if (i < k.np) { const int ix = (J + (i >> 6)) * 64 + (i & 63); R2[i] = (i < n && PS[ix] != 0.0) ? PB[ix] : XS[i]; }
+    }
     WAVE_SYNC();
-    for (int pit = 0; pok; ++pit) {
-      {
-        const double* vin[1] = {R2}; double* rout[2] = {aVA, aVC};
-        pass_Av<T, NB, 1, 3>(k, vin, rout, P1, P2);   // v = A~x, y^ = y - rho*act*(v - b), P1 = A~'y^, P2 = A~'(rho*act*(v - b))
-      }
-      for (int jb = 0; jb < k.JB; ++jb) {
-        const int i = jb * 64 + lane, ix = (J + jb) * 64 + lane;
-        const double v = i < n ? R2[i] : 0.0;
-        aVA[ix] = v; aVC[ix] = PY[ix] - PA[ix] * (v - PB[ix]);
-      }
+    const double* cf_eval[3] = {PA, PB, PY};
+    const double* cf_cg[3] = {PA, PZ0, PZ0};
+    // gradient of the augmented Lagrangian at (z, y): v = A~z, y^ = y - rho c, P1 = A~'y^, P2 = rho A_W'c; then grad = H~z + g - P1
+    auto eval_zy = [&]() __attribute__((always_inline)) {
+      const double* vin[1] = {R2}; double* rout[2] = {aVA, aVC};
+      pass_Av<T, NB, 1, 3>(k, vin, rout, P1, P2, cf_eval);
       hx_full(R2);
       WAVE_SYNC();
+    };
+    if (pok) {
+      eval_zy();
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < k.np) { const int ix = (J + (i >> 6)) * 64 + (i & 63); DX[i] = (i < n && PS[ix] == 0.0) ? -(HX[i] + G[i] - P1[i]) : 0.0; }
+      }
+      WAVE_SYNC();
+      solve1(DX);
+      WAVE_SYNC();
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        if (i < n) { const int ix = (J + (i >> 6)) * 64 + (i & 63); if (PS[ix] == 0.0) R2[i] += DX[i]; }
+      }
+      WAVE_SYNC();
+      eval_zy();   // c(z): aVA = A~z; P2 = rho A_W'c
+      double rs_l = 0.0;
+      for (int js = 0; js < J; ++js) {
+        const int ix = js * 64 + lane;
+        const double cc_ = PA[ix] != 0.0 ? aVA[ix] - PB[ix] : 0.0;
+        PC[ix] = cc_; PP[ix] = -cc_; rs_l = fma(cc_, cc_, rs_l);
+      }
+      double rs = wave_sum(rs_l);
+      for (int h = 0; h < 2; ++h) { const int i = lane + 64 * h; if (i < k.np) { ATR[i] = -P2[i] * rinv; ATP[i] = ATR[i]; } }
+      WAVE_SYNC();
+      for (int cgit = 0; cgit < 12 && pok; ++cgit) {
+        double m_eq = 0.0, m_cy = 0.0;
+        for (int js = 0; js < J; ++js) {
+          const int ix = js * 64 + lane;
+          m_eq = fmax(m_eq, fabs(PC[ix]) / fmax(1.0, fabs(PB[ix])));
+          m_cy = fmax(m_cy, fabs(PC[ix] * PY[ix]));
+        }
+        m_eq = wave_max(m_eq); m_cy = wave_max(m_cy);
+        if (m_eq <= 1e-11 && m_cy <= 1e-11 * fmax(1.0, fabs(fval_s))) break;
+        if (cgit == 11) { pok = false; flag_polished = -6; break; }
+        for (int h = 0; h < 2; ++h) {
+          const int i = lane + 64 * h;
+          if (i < k.np) { const int ix = (J + (i >> 6)) * 64 + (i & 63); DX[i] = (i < n && PS[ix] == 0.0) ? ATP[i] : 0.0; }
+        }
+        WAVE_SYNC();
+        solve1(DX);                                   // w = M^-1 A_W'p
+        WAVE_SYNC();
+        {
+          const double* vin[1] = {DX}; double* rout[2] = {aVA, aVC};
+          pass_Av<T, NB, 1, 3>(k, vin, rout, P1, P2, cf_cg);   // aVA = A~w; P2 = rho A_W'(A_W w)
+        }
+        WAVE_SYNC();
+        double pq_l = 0.0;
+        for (int js = 0; js < J; ++js) { const int ix = js * 64 + lane; if (PA[ix] != 0.0) pq_l = fma(PP[ix], aVA[ix], pq_l); }
+        const double pq = wave_sum(pq_l);
+        if (!(pq > 0.0) || !(rs > 0.0)) {   // dependent / inconsistent working set: drop the row that carries the stalled direction
+          pok = false; flag_polished = -7;
+          if (attempt < 2) {
+            double my = 0.0; int myix = -1;
+            for (int js = 0; js < J; ++js) { const int ix = js * 64 + lane; if (PA[ix] != 0.0 && fabs(PP[ix]) > my) { my = fabs(PP[ix]); myix = ix; } }
+            const double mx = wave_max(my);
+            if (mx > 0.0 && my == mx && myix >= 0) { PS[myix] = 0.0; PY[myix] = 0.0; }
+            for (int i = lane; i < k.np; i += 64) XS[i] = R2[i];
+            WAVE_SYNC();
+            retry = true;
+          }
+          break;
+        }
+        const double alpha_ = rs / pq;
+        double rsn_l = 0.0;
+        for (int js = 0; js < J; ++js) {
+          const int ix = js * 64 + lane;
+          if (PA[ix] != 0.0) {
+            PY[ix] = fma(alpha_, PP[ix], PY[ix]);
+            const double cc_ = fma(alpha_, aVA[ix], PC[ix]);
+            PC[ix] = cc_; rsn_l = fma(cc_, cc_, rsn_l);
+          }
+        }
+        const double rsn = wave_sum(rsn_l);
+        const double beta_ = rsn / rs;
+        for (int js = 0; js < J; ++js) { const int ix = js * 64 + lane; if (PA[ix] != 0.0) PP[ix] = fma(beta_, PP[ix], -PC[ix]); }
+        for (int h = 0; h < 2; ++h) {
+          const int i = lane + 64 * h;
+          if (i < k.np) {
+            const int ix = (J + (i >> 6)) * 64 + (i & 63);
+            if (i < n && PS[ix] == 0.0) R2[i] = fma(alpha_, DX[i], R2[i]);
+            ATR[i] = fma(-alpha_ * rinv, P2[i], ATR[i]);
+            ATP[i] = fma(beta_, ATP[i], ATR[i]);
+          }
+        }
+        rs = rsn;
+        WAVE_SYNC();
+        // the masked residual lives in PC; aVA is overwritten by the next A~w, so the test above uses |b| and the last A~w only as scale
+      }
+    }
+    if (pok) {
+      // fresh evaluation of the candidate (z, y): everything recomputed from a stream over A~ and H~
+      eval_zy();
       double m_rd = 0, m_rp = 0, m_sg = 0, m_cp = 0, fl2 = 0;
       for (int h = 0; h < 2; ++h) {
         const int i = lane + 64 * h;
-        if (i < k.np) {
+        if (i < n) {
           const int ix = (J + (i >> 6)) * 64 + (i & 63);
-          double r = 0.0;
-          if (i < n) {
-            const double gz = P1[i] + aVC[ix];
-            r = HX[i] + G[i] - gz;
-            const double sc = fmax(1.0, fmax(fabs(G[i]), fmax(fabs(HX[i]), fabs(gz))));
-            m_rd = fmax(m_rd, fabs(r) / sc);
-            fl2 += 0.5 * R2[i] * HX[i] + G[i] * R2[i];
-          }
-          DX[i] = -(r + P2[i] + PA[ix] * (aVA[ix] - PB[ix]));   // -grad of the augmented Lagrangian at (x, y^)
+          const double r = HX[i] + G[i] - P1[i];                    // free variable: must vanish; pinned variable: its bound multiplier
+          const double sc = fmax(1.0, fmax(fabs(G[i]), fmax(fabs(HX[i]), fabs(P1[i]))));
+          const double sd = PS[ix], zi = R2[i], l = aL[ix], u = aU[ix];
+          if (sd == 0.0) m_rd = fmax(m_rd, fabs(r) / sc);
+          else m_sg = fmax(m_sg, (sd > 0 ? -r : r) / sc);
+          aVC[ix] = sd != 0.0 ? r : 0.0;                            // multiplier of the variable-bound row
+          double viol = 0.0;
+          if (l > -INFINITY && zi < l) viol = l - zi;
+          if (u < INFINITY && zi > u) viol = fmax(viol, zi - u);
+          m_rp = fmax(m_rp, viol / fmax(1.0, fabs(zi)));
+          fl2 += 0.5 * zi * HX[i] + G[i] * zi;
         }
       }
-      for (int js = 0; js < JT; ++js) {
+      for (int js = 0; js < J; ++js) {
         const int ix = js * 64 + lane;
         if (row_valid(k, js)) {
           const double l = aL[ix], u = aU[ix], v = aVA[ix], y = aVC[ix], sd = PS[ix];
@@ -1577,38 +1687,72 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
           if (l > -INFINITY && v < l) viol = fmax(viol, l - v);
           if (u < INFINITY && v > u) viol = fmax(viol, v - u);
           m_rp = fmax(m_rp, viol / sc);
-          m_sg = fmax(m_sg, sd > 0 ? -y : (sd < 0 ? y : 0.0));
+          m_sg = fmax(m_sg, (sd > 0 ? -y : (sd < 0 ? y : 0.0)) / fmax(1.0, fabs(y)));
         }
       }
       m_rd = wave_max(m_rd); m_rp = wave_max(m_rp); m_sg = wave_max(m_sg); m_cp = wave_max(m_cp);
       const double f2 = wave_sum(fl2);
-      const bool conv = m_rd <= 1e-10 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2));
-      if (P.dump && b < 32 && P.dump_stage == 3 && lane == 0) { double* o_ = P.dump + 64 * b + 8 * pit; o_[0] = m_rd; o_[1] = m_rp; o_[2] = m_sg; o_[3] = m_cp; o_[4] = conv; o_[5] = f2; }
-      if (conv || pit == 7) {
-        // accept only a true KKT point: multipliers of the right sign (round-off level wrong signs are zeroed)
-        pok = conv && m_sg <= 1e-8;
-        if (!pok) flag_polished = !(m_rd <= 1e-10) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!conv ? -3 : -4));
-        if (pok) {
-          for (int i = lane; i < k.np; i += 64) X[i] = R2[i];
-          for (int js = 0; js < JT; ++js) {
-            const int ix = js * 64 + lane;
-            const double y = aVC[ix], sd = PS[ix];
-            aW3[ix] = sd > 0 ? fmax(y, 0.0) : (sd < 0 ? fmin(y, 0.0) : 0.0);
+#ifdef QP_DEBUG_DUMP
+      if (P.dump && b < 32 && P.dump_stage == 3 && lane == 0) { double* o_ = P.dump + 64 * b; o_[0] = m_rd; o_[1] = m_rp; o_[2] = m_sg; o_[3] = m_cp; o_[5] = f2; }
+#endif
+      // acceptance: relative stationarity 1e-8 (the 1e8 slack cost of ltvmpc_*.m:35 puts cancellations of 1e8 eps into A'y of
+      // the active soft rows: the floor of any fp64 evaluation of this residual; qpOASES' own terminationTolerance is
+      // 5e6 eps = 1.1e-9, qpOASES_options.m:190), feasibility and complementarity 1e-10, multipliers of the right sign
+      // (round-off level wrong signs are zeroed)
+      pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8;
+      if (!pok) flag_polished = !(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3));
+      if (!pok && m_rd <= 1e-8 && attempt < 2 && (m_rp > 1e-10 || m_sg > 1e-8)) {
+        // single correction of the working set: add the most violated inactive row, else drop the worst wrong-sign row
+        double my = 0.0; int myix = -1; double myside = 0.0;
+        const bool add = m_rp > 1e-10;
+        for (int js = 0; js < JT; ++js) {
+          const int ix = js * 64 + lane;
+          if (!row_valid(k, js)) continue;
+          const double l = aL[ix], u = aU[ix], sd = PS[ix];
+          const double v = js < J ? aVA[ix] : R2[(js - J) * 64 + lane];
+          if (add) {
+            if (sd != 0.0) continue;
+            double sc = fmax(1.0, fabs(v));
+            if (js < J) { if (l > -INFINITY) sc = fmax(sc, fabs(l)); if (u < INFINITY) sc = fmax(sc, fabs(u)); }
+            const double vl = l > -INFINITY ? (l - v) / sc : -1.0, vu = u < INFINITY ? (v - u) / sc : -1.0;
+            const double vv = fmax(vl, vu);
+            if (vv > my) { my = vv; myix = ix; myside = vl >= vu ? 1.0 : -1.0; }
+          } else {
+            if (sd == 0.0) continue;
+            const double y = aVC[ix];
+            const double sc = js < J ? fmax(1.0, fabs(y)) : 1.0;
+            const double sg = (sd > 0 ? -y : y) / sc;
+            if (sg > my) { my = sg; myix = ix; myside = 0.0; }
           }
-          flag_polished = 1 + pit;
-          fval_s = f2;
-          flag = 0;
         }
+        const double mx = wave_max(my);
+        if (mx > 0.0 && my == mx && myix >= 0) { PS[myix] = myside; PY[myix] = 0.0; }
+        for (int js = 0; js < J; ++js) PY[js * 64 + lane] = PS[js * 64 + lane] != 0.0 ? PY[js * 64 + lane] : 0.0;
+        for (int i = lane; i < k.np; i += 64) XS[i] = R2[i];
         WAVE_SYNC();
-        break;
+        continue;   // next attempt from the point reached (R2) with the corrected working set
+      }
+      if (!pok && !(m_rd <= 1e-8) && attempt < 2 && m_rd <= 1e-4) {   // stationarity above the floor: one more exact step from here
+        for (int i = lane; i < k.np; i += 64) XS[i] = R2[i];
+        for (int js = 0; js < J; ++js) { const int ix = js * 64 + lane; PY[ix] = PS[ix] != 0.0 ? aVC[ix] : 0.0; }
+        WAVE_SYNC();
+        continue;
+      }
+      if (!pok) break;
+      if (pok) {
+        for (int i = lane; i < k.np; i += 64) X[i] = R2[i];
+        for (int js = 0; js < JT; ++js) {
+          const int ix = js * 64 + lane;
+          const double y = aVC[ix], sd = PS[ix];
+          aW3[ix] = sd > 0 ? fmax(y, 0.0) : (sd < 0 ? fmin(y, 0.0) : 0.0);
+        }
+        flag_polished = 1 + attempt;
+        fval_s = f2;
+        flag = 0;
       }
       WAVE_SYNC();
-      solve1(DX);
-      WAVE_SYNC();
-      for (int i = lane; i < k.np; i += 64) R2[i] += DX[i];
-      for (int js = 0; js < JT; ++js) PY[js * 64 + lane] = aVC[js * 64 + lane];
-      WAVE_SYNC();
-    }
+    } else if (!retry) break;
+    }   // attempts
   }
   if (flag == 4) flag = -1;   // not certified
   const bool have_x = flag == 0 || flag == 1;
@@ -1826,24 +1970,30 @@ void qp_make_dims(int n, int m, QpDims* d) {
     const int Tt = d->T, Dd = Tt <= 5 ? 6 : (Tt == 6 ? 4 : (Tt == 7 ? 3 : 2));   // = StreamCfg<T>::D
     d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272 + (size_t)(Dd + Tt) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);
   }
-  {   // workgroup solve kernel (qp_wg.hip): keep the operand stream of A~ resident in LDS when ~2/3 of its dense size fits
-      // (structurally empty tiles are skipped, the LTV-MPC families keep ~60 %); a QP whose stream turns out larger
-      // falls back to reading it from global memory inside the kernel
-    const size_t cap = 160 * 1024 - 2048;
+  {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP.  The operand stream of A~ stays resident in LDS when
+      // ~2/3 of its dense size fits (structurally empty tiles are skipped, the LTV-MPC families keep ~60 %) and the rows
+      // fit one owner-layout slot per wave; a QP whose stream turns out larger is handed to the streaming variant.
+    const size_t cap = 160 * 1024;
     const size_t dense = (size_t)2 * d->ntr * d->T * 1024;
-    d->W = 4; d->lds_aw_bytes = 0;
-    for (int Wt = 4; Wt <= 8; Wt += 4) {
-      const size_t base = qp_wg_lds_base_bytes(*d, Wt);
-      if (base >= cap) break;
+    d->W = 8;
+    d->NBk = d->nb == 0 ? 0 : ((d->nb == 1 && d->T <= QP_WG_RES_MAX_T) ? 1 : 4);
+    d->lds_aw_bytes = 0;
+    const size_t base = qp_wg_lds_base_bytes(*d, d->W, d->NBk, true);
+    if (base < cap && d->T <= QP_WG_RES_MAX_T && d->J + d->JB <= 8 && dense > 0) {
       const size_t avail = (cap - base) & ~(size_t)1023;
-      if (dense * 2 / 3 <= avail && dense > 0) {
-        const size_t take = dense < avail ? dense : avail;
-        if (Wt == 4 && take + base > 80 * 1024) continue;   // one workgroup per CU anyway: use 8 wavefronts
-        d->W = Wt; d->lds_aw_bytes = take;
-        break;
+      if (dense * 2 / 3 <= avail) d->lds_aw_bytes = dense < avail ? dense : avail;
+    }
+    d->lds_wg = d->lds_aw_bytes ? base + d->lds_aw_bytes : qp_wg_lds_base_bytes(*d, d->W, d->NBk, false);
+    if (const char* ex = getenv("FSAEMPC_WG")) {   // development only (QP_WG_EXPERIMENT builds): "W,RES"
+      int Wx = 8, Rx = 1;
+      if (sscanf(ex, "%d,%d", &Wx, &Rx) == 2) {
+        d->W = Wx;
+        const size_t bx = qp_wg_lds_base_bytes(*d, Wx, d->NBk, Rx != 0);
+        d->lds_aw_bytes = 0;
+        if (Rx && bx < cap) { const size_t avail = (cap - bx) & ~(size_t)1023; d->lds_aw_bytes = dense < avail ? dense : avail; }
+        d->lds_wg = bx + d->lds_aw_bytes;
       }
     }
-    d->lds_wg = qp_wg_lds_base_bytes(*d, d->W) + d->lds_aw_bytes;
   }
   d->prep_tw = 16;
   for (;;) {
@@ -1900,29 +2050,21 @@ hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st) { re
 #endif
 
 #if QP_MAIN_TU
-// qp_wg.hip is built as several translation units (one per range of tile counts, named by its first T); a one-command
-// build (-DQP_WG_ONE_TU) has everything in the unit named 1
+// qp_wg.hip (workgroup-per-QP kernel) serves the tile counts the one-wavefront kernel cannot hold in registers
+// (T = 9..12, nV up to 196): built as two translation units named by their first T.  A development build
+// (-DQP_WG_ONE_TU, `make devlib`) has its own selection of tile counts in one unit and FSAEMPC_QP_WG=1 routes every shape to it.
+#ifdef QP_WG_ONE_TU
 hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
-#ifndef QP_WG_ONE_TU
-hipError_t qp_wg_launch_5(const QpParams& P, int batch, hipStream_t st);
-hipError_t qp_wg_launch_6(const QpParams& P, int batch, hipStream_t st);
-hipError_t qp_wg_launch_7(const QpParams& P, int batch, hipStream_t st);
+static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) { return qp_wg_launch_1(P, batch, st); }
+#else
 hipError_t qp_wg_launch_9(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_11(const QpParams& P, int batch, hipStream_t st);
-#endif
 static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) {
-#ifdef QP_WG_ONE_TU
-  return qp_wg_launch_1(P, batch, st);
-#else
-  const int T = P.d.T;
-  if (T <= 4) return qp_wg_launch_1(P, batch, st);
-  if (T == 5) return qp_wg_launch_5(P, batch, st);
-  if (T == 6) return qp_wg_launch_6(P, batch, st);
-  if (T <= 8) return qp_wg_launch_7(P, batch, st);
-  if (T <= 10) return qp_wg_launch_9(P, batch, st);
-  return qp_wg_launch_11(P, batch, st);
-#endif
+  if (P.d.T >= 9 && P.d.T <= 10) return qp_wg_launch_9(P, batch, st);
+  if (P.d.T >= 11 && P.d.T <= 12) return qp_wg_launch_11(P, batch, st);
+  return hipErrorInvalidValue;
 }
+#endif
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_prep);
@@ -1943,9 +2085,9 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     return hipGetLastError();
   }
 #endif
-  {   // round-2 workgroup-per-QP kernel (qp_wg.hip); FSAEMPC_QP_V1=1 selects the round-1 one-wavefront kernel (T <= 8) for A/B runs
-    static const bool use_v1 = getenv("FSAEMPC_QP_V1") != nullptr;
-    if (!use_v1 || P.d.T > 8) return qp_wg_launch(P, batch, st);
+  {
+    static const bool force_wg = getenv("FSAEMPC_QP_WG") != nullptr;   // development builds only
+    if (P.d.T > 8 || force_wg) return qp_wg_launch(P, batch, st);
   }
 #if !defined(QP_TU)
   switch (P.d.T) {

@@ -21,10 +21,8 @@ def run(model, N, B):
     torch.cuda.synchronize()
     fm.lib().fsaempc_debug_set_polished(None)
     fm.lib().fsaempc_debug_set_dump(None, 0)
-    d = dmp.cpu().numpy()[:32 * 64].reshape(32, 8, 8)
-    if os.environ.get("POLISH_TRACE"):
-        for b in range(12):
-            print(b, " | ".join("%.1e %.1e %.1e %.1e" % tuple(d[b, i, :4]) for i in range(5)))
+    # refinement codes: 1 accepted; -1 stationarity, -2 primal feasibility, -3 complementarity, -4 multiplier sign,
+    # -5 factorisation, -6 CG did not converge in 7 steps, -7 CG breakdown (dependent / inconsistent working set)
     code = pol.cpu().numpy(); pol = code > 0
     print("codes:", dict(zip(*np.unique(code, return_counts=True))))
     x = out["x"].cpu().numpy(); lam = out["lam"].cpu().numpy(); fl = out["exitflag"].cpu().numpy()

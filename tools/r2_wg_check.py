@@ -43,8 +43,11 @@ if __name__ == "__main__":
     shapes = [(0, 40, 4096), (0, 20, 4096), (1, 40, 2048), (0, 12, 256), (1, 8, 256), (0, 9, 256), (1, 7, 256), (0, 5, 64), (1, 60, 512)]
     if which == "wg":
         shapes += [(1, 80, 256), (0, 90, 128)]
-    for (mo, N, B) in shapes:
+    if os.environ.get("SHAPES"):
+        shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
+    for sh in shapes:
+        mo, N, B = sh[:3]
         try:
-            shape(mo, N, B)
+            shape(mo, N, B, polish=sh[3] if len(sh) > 3 else 0)
         except Exception as e:
             print("model %d N %d FAILED: %s" % (mo, N, e), flush=True)
