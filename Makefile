@@ -5,20 +5,20 @@ CSRC    := fsae-mpc_amd/csrc
 LIBDIR  := fsae-mpc_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
-all: $(LIBDIR)/libfsaempc.so oracle o1
+all: $(LIBDIR)/libfsaempc.so oracle o1 dbg
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h $(CSRC)/plant.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-# qp_solver.hip is compiled as five translation units (see the note in the file): main + four groups of tile counts
-QPOBJ := $(LIBDIR)/qp_solver_tu0.o $(LIBDIR)/qp_solver_tu1.o $(LIBDIR)/qp_solver_tu2.o $(LIBDIR)/qp_solver_tu3.o $(LIBDIR)/qp_solver_tu4.o
+# qp_solver.hip is compiled as three translation units (see the note in the file): main + two groups of tile counts (T = 1..4, T = 5)
+QPOBJ := $(LIBDIR)/qp_solver_tu0.o $(LIBDIR)/qp_solver_tu1.o $(LIBDIR)/qp_solver_tu2.o
 $(LIBDIR)/qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_TU=$* -c $< -o $@
 
-# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 9..12) is compiled once per range of tile counts (lo_hi)
-WGOBJ := $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
+# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 1..12) is compiled once per range of tile counts (lo_hi)
+WGOBJ := $(LIBDIR)/qp_wg_1_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_7_8.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
 $(LIBDIR)/qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*)) -c $< -o $@
@@ -46,12 +46,32 @@ $(LIBDIR)/libfsaempc_dev.so: $(LIBDIR)/dev_qp_solver.o $(LIBDIR)/dev_qp_wg.o $(L
 $(LIBDIR)/libfsaempc_devst.so: $(LIBDIR)/dev_qp_solver.o $(LIBDIR)/devst_qp_wg.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-# guard build: the same sources at -O1 (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build compares the two on the
-# GPU; see DESIGN.md "Known fragility").  Only T = 5 and T = 8 kernels (the headline shape and the spill-heavy one).
-o1: $(LIBDIR)/libfsaempc_O1.so
-$(LIBDIR)/libfsaempc_O1.so: $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h include/fsaempc.h
+# diagnostic library with the in-kernel dump hooks of both kernels (tests/test_gpu_parity.py::test_01_normal_matrix_dump_matches_numpy); T <= 5
+DBGOBJ := $(LIBDIR)/dbg_qp_solver_tu0.o $(LIBDIR)/dbg_qp_solver_tu1.o $(LIBDIR)/dbg_qp_solver_tu2.o $(LIBDIR)/dbg_qp_wg_1_5.o
+$(LIBDIR)/dbg_qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -O1 -std=c++17 -fPIC -Iinclude -I$(CSRC) -DQP_O1_GUARD=1 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
+	$(HIPCC) $(HIPFLAGS) -DQP_DEBUG_DUMP -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*)) -c $< -o $@
+$(LIBDIR)/dbg_qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DQP_DEBUG_DUMP -DQP_TU=$* -c $< -o $@
+dbg: $(LIBDIR)/libfsaempc_dbg.so
+$(LIBDIR)/libfsaempc_dbg.so: $(DBGOBJ) $(filter-out $(LIBDIR)/qp_wg_1_5.o,$(WGOBJ)) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+# guard build: the solver sources at -O1, every instantiated (T, NB) (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build
+# compares the two builds on the GPU; see DESIGN.md "Build-variant fragility")
+O1FLAGS := --offload-arch=$(ARCH) -O1 -std=c++17 -fPIC -Iinclude -I$(CSRC)
+O1OBJ := $(LIBDIR)/o1_qp_solver_tu0.o $(LIBDIR)/o1_qp_solver_tu1.o $(LIBDIR)/o1_qp_solver_tu2.o \
+         $(LIBDIR)/o1_qp_wg_1_5.o $(LIBDIR)/o1_qp_wg_6_6.o $(LIBDIR)/o1_qp_wg_7_8.o $(LIBDIR)/o1_qp_wg_9_10.o $(LIBDIR)/o1_qp_wg_11_12.o
+$(LIBDIR)/o1_qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(O1FLAGS) -DQP_TU=$* -c $< -o $@
+$(LIBDIR)/o1_qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(O1FLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*)) -c $< -o $@
+o1: $(LIBDIR)/libfsaempc_O1.so
+$(LIBDIR)/libfsaempc_O1.so: $(O1OBJ) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 oracle:
 	$(MAKE) -C oracle
@@ -59,4 +79,4 @@ oracle:
 clean:
 	rm -rf $(LIBDIR)/*.o $(LIBDIR)/*.so
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean stamps o1 devlib
+.PHONY: all oracle clean stamps o1 devlib dbg

@@ -11,16 +11,20 @@ EXPORTS = [
     "fsaempc_qp_default_opts", "fsaempc_qp_workspace_bytes", "fsaempc_qp_solve_batch_device", "fsaempc_qp_solve_batch",
     "fsaempc_ltv_nx", "fsaempc_ltv_nV", "fsaempc_ltv_nC", "fsaempc_ltv_build_qp_batch_device",
     "fsaempc_ltv_workspace_bytes", "fsaempc_ltv_step_batch_device", "fsaempc_last_error", "fsaempc_selftest_mfma",
-    "fsaempc_debug_set_dump", "fsaempc_debug_set_polished", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
+    "fsaempc_debug_set_dump", "fsaempc_qp_solve_batch_device_aux", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
     "fsaempc_seq_init", "fsaempc_seq_hotstart", "fsaempc_seq_hotstart_matrices", "fsaempc_seq_cleanup",
     "fsaempc_obtain_reference_batch_device", "fsaempc_reference_live_batch_device",
-    "fsaempc_cl_pre_batch_device", "fsaempc_cl_plant_batch_device",
+    "fsaempc_cl_pre_batch_device", "fsaempc_cl_plant_batch_device", "fsaempc_cl_accept_batch_device",
 ]
 
 
 class QpOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("tol_loose", C.c_double), ("tol_x", C.c_double), ("inf_bound", C.c_double),
                 ("max_iter", C.c_int), ("polish", C.c_int)]
+
+
+class QpAux(C.Structure):
+    _fields_ = [("kkt", C.c_void_p), ("polished", C.c_void_p)]
 
 
 class QpDesc(C.Structure):
@@ -54,6 +58,7 @@ def lib():
         L.fsaempc_ltv_workspace_bytes.restype = C.c_longlong
         vp, ll = C.c_void_p, C.c_longlong
         L.fsaempc_qp_solve_batch_device.argtypes = [C.POINTER(QpDesc)] + [vp] * 7 + [C.POINTER(QpOpts)] + [vp] * 5 + [vp, ll, vp]
+        L.fsaempc_qp_solve_batch_device_aux.argtypes = [C.POINTER(QpDesc)] + [vp] * 7 + [C.POINTER(QpOpts)] + [vp] * 5 + [C.POINTER(QpAux), vp, ll, vp]
         L.fsaempc_qp_solve_batch.argtypes = [C.POINTER(QpDesc)] + [vp] * 7 + [C.POINTER(QpOpts)] + [vp] * 5
         L.fsaempc_ltv_build_qp_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [vp] * 7 + [vp] * 3 + [vp]
         L.fsaempc_ltv_step_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [C.POINTER(QpOpts)] + [vp] * 6 + [vp, ll, vp]
@@ -61,8 +66,8 @@ def lib():
         L.fsaempc_reference_live_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp, vp]
         L.fsaempc_cl_pre_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Spline), vp, vp, C.c_int, vp, vp, vp, vp]
         L.fsaempc_cl_plant_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+        L.fsaempc_cl_accept_batch_device.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.fsaempc_debug_set_dump.argtypes = [vp, C.c_int]
-        L.fsaempc_debug_set_polished.argtypes = [vp]
         _LIB = L
     return _LIB
 

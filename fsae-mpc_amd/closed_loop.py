@@ -10,8 +10,9 @@ from .ltvmpc import LtvBatch, dims
 
 class ClosedLoop:
     """B cars on one track.  cart0: (B, 7) Cartesian states [x, y, theta, x_d, y_d, theta_d, delta] (main.m:63 starts
-    from zeros(7,1)).  step() advances every car by one MPC period dt; cars that completed the lap (s >= L) or whose
-    QP did not solve keep their state for that step."""
+    from zeros(7,1)).  step() advances every car by one MPC period dt, all on the device and without reading anything
+    back; like the reference (main.m:122-126, 163-175) a car keeps driving after an abnormal solver exit -- on its last good
+    plan -- and the exit flags are only tallied.  Cars that completed the lap (s >= L) or left the track keep their state."""
 
     def __init__(self, model, N, dt, track, cart0, target_vel=20.0, device="cuda:0", options=None, integrator=-1):
         import torch
@@ -51,7 +52,7 @@ class ClosedLoop:
         check(rc, "fsaempc_cl_pre_batch_device")
 
     def plant(self, exitflag, stream=None):
-        P = lambda t: C.c_void_p(t.data_ptr())
+        P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         rc = lib().fsaempc_cl_plant_batch_device(self.model, self.N, C.c_double(self.dt), self.B, P(self.cart), P(self.pid), P(self.x_opt),
                                                  P(self.finished), P(exitflag), P(self.u_last), self._stream(stream))
         check(rc, "fsaempc_cl_plant_batch_device")
@@ -60,9 +61,46 @@ class ClosedLoop:
         torch = self.torch
         self.pre(stream)
         out = self.mpc.step(self.x0, self.x_ref, self.x_opt, self.u_opt, stream=stream)   # linearised about the previous plan (main.m:121-125)
-        ok = (out["exitflag"] == 0).view(-1, 1, 1)
-        self.x_opt = torch.where(ok, out["x_opt"].view(self.B, self.N, self.nx), self.x_opt).contiguous()
-        self.u_opt = torch.where(ok, out["u_opt"].view(self.B, self.N, 2), self.u_opt).contiguous()
-        self.plant(out["exitflag"], stream)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        check(lib().fsaempc_cl_accept_batch_device(self.model, self.N, self.B, P(out["x_opt"]), P(out["u_opt"]), P(out["exitflag"]), P(self.x_opt), P(self.u_opt),
+                                                   self._stream(stream)), "fsaempc_cl_accept_batch_device")
+        self.plant(None, stream)
         self.steps += 1
         return out
+
+
+def monte_carlo_carts(track, B, seed):
+    """Initial Cartesian states of BASELINE configs[3]: s0 = u*L, lateral +-0.5 m, heading +-0.1 rad,
+    speed U[0,15]; numpy PCG64(seed).  Returns (cart (B,7), s0 (B,))."""
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(0, track.L, B); n = rng.uniform(-0.5, 0.5, B); dth = rng.uniform(-0.1, 0.1, B); v = rng.uniform(0, 15, B)
+
+    def ev(P, t):   # the Bezier table on the host (same formulas as interpolate_spline / interpolate_spline_d); P is M x 4
+        r = np.mod(t, track.dl * track.M); i = np.minimum(np.floor(r / track.dl).astype(int), track.M - 1); u = r / track.dl - i; w = 1 - u
+        val = P[i, 0] * w ** 3 + 3 * P[i, 1] * w * w * u + 3 * P[i, 2] * w * u * u + P[i, 3] * u ** 3
+        d = (-3 * w * w * P[i, 0] + 3 * (3 * u * u - 4 * u + 1) * P[i, 1] + 3 * (2 * u - 3 * u * u) * P[i, 2] + 3 * u * u * P[i, 3]) / track.dl
+        return val, d
+    x, xd = ev(track.xP, s); y, yd = ev(track.yP, s)
+    nrm = np.hypot(xd, yd)
+    cart = np.zeros((B, 7))
+    cart[:, 0] = x - yd / nrm * n; cart[:, 1] = y + xd / nrm * n; cart[:, 2] = np.arctan2(yd, xd) + dth; cart[:, 3] = v
+    return cart, s
+
+
+def monte_carlo(model, N, track, B, steps, seed=20190, options=None, device="cuda:0"):
+    """Closed-loop Monte-Carlo: B cars from random initial states, `steps` receding-horizon steps, device-resident loop.
+    Returns the ClosedLoop and the per-step tallies (exit flags, iteration counts, driving mask), read back once at the end --
+    the reference reports exactly this tally as "abnormal exits %" (main.m:209,222)."""
+    import torch
+    cart0, s_init = monte_carlo_carts(track, B, seed)
+    cl = ClosedLoop(model, N, 0.05, track, cart0, options=options, device=device)
+    cl.x_opt[:, :, 0] += torch.from_numpy(s_init).to(cl.device)[:, None]        # start the closest-point search near the car
+    cl.x_opt[:, :, 3] += torch.from_numpy(cart0[:, 3]).to(cl.device)[:, None]   # and the first linearisation at its speed
+    flags = torch.zeros((steps, B), dtype=torch.int32, device=cl.device)
+    iters = torch.zeros((steps, B), dtype=torch.int32, device=cl.device)
+    active = torch.zeros((steps, B), dtype=torch.bool, device=cl.device)
+    for t in range(steps):
+        out = cl.step()
+        flags[t] = out["exitflag"]; iters[t] = out["iter"]; active[t] = cl.finished == 0
+    torch.cuda.synchronize(cl.device)
+    return cl, flags.cpu().numpy(), iters.cpu().numpy(), active.cpu().numpy()

@@ -15,7 +15,7 @@
 
 namespace {
 thread_local char g_err[512] = "";
-double* g_dump = nullptr; int g_dump_stage = 0, g_dump_iter = 0; int* g_polished = nullptr;
+double* g_dump = nullptr; int g_dump_stage = 0, g_dump_iter = 0;   // diagnostic builds only
 bool g_timing = false; hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 
 int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); return code; }
@@ -47,6 +47,13 @@ int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc, const double* H, 
                                   const double* lb, const double* ub, const double* lbA, const double* ubA,
                                   const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
                                   double* lambda, void* workspace, long long workspace_bytes, void* stream) {
+  return fsaempc_qp_solve_batch_device_aux(desc, H, g, A, lb, ub, lbA, ubA, opts, x, fval, exitflag, iter, lambda, nullptr, workspace, workspace_bytes, stream);
+}
+
+int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double* H, const double* g, const double* A,
+                                      const double* lb, const double* ub, const double* lbA, const double* ubA,
+                                      const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
+                                      double* lambda, const fsaempc_qp_aux* aux, void* workspace, long long workspace_bytes, void* stream) {
   if (!desc || !H || !g || !lb || !ub || !x || !fval || !exitflag || !iter || !workspace) return fail(FSAEMPC_ERR_ARG, "null argument");
   if (desc->nV <= 0 || desc->nC < 0 || desc->batch < 0) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
   if (desc->nC > 0 && (!A || !lbA || !ubA)) return fail(FSAEMPC_ERR_ARG, "nC > 0 needs A, lbA, ubA");
@@ -56,10 +63,11 @@ int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc, const double* H, 
   QpParams P; memset(&P, 0, sizeof(P));
   qp_make_dims(desc->nV, desc->nC, &P.d);
   if ((long long)(P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
-  if ((P.d.T > 8 ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024 || (P.d.T > 8 && P.d.J + P.d.JB > 32)) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels (nV > 128 supports up to ~1850 constraint rows)");
+  const bool wg = P.d.T > 5 || P.d.nb == 0;   // kernel selection of qp_launch
+  if ((wg ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024 || (wg && P.d.J + P.d.JB > 32)) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels (the workgroup kernel supports up to ~1850 constraint rows)");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
-  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = g_polished;
+  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr;
   P.shared_HA = desc->shared_HA;
   P.dump = g_dump; P.dump_stage = g_dump_stage & 0xff; P.dump_iter = g_dump_stage >> 8;
   hipError_t e;
@@ -293,6 +301,15 @@ int fsaempc_cl_plant_batch_device(int model, int N, double dt, int batch, double
   return 0;
 }
 
+int fsaempc_cl_accept_batch_device(int model, int N, int batch, const double* x_new, const double* u_new, const int* exitflag, double* x_keep, double* u_keep, void* stream) {
+  if (!x_new || !u_new || !x_keep || !u_keep) return fail(FSAEMPC_ERR_ARG, "null argument");
+  if (model != FSAEMPC_MODEL_KINEMATIC && model != FSAEMPC_MODEL_DYNAMIC) return fail(FSAEMPC_ERR_ARG, "unknown model");
+  if (N <= 0 || batch < 0) return fail(FSAEMPC_ERR_ARG, "bad dimensions");
+  hipError_t e = cl_accept_launch(fsaempc_ltv_nx(model) * N, 2 * N, batch, x_new, u_new, exitflag, x_keep, u_keep, (hipStream_t)stream);
+  if (e != hipSuccess) return hipfail(e, "cl_accept_launch");
+  return 0;
+}
+
 int fsaempc_selftest_mfma(void) {
   int cnt = 0;
   hipError_t e = hipGetDeviceCount(&cnt);
@@ -304,7 +321,6 @@ int fsaempc_selftest_mfma(void) {
 }
 
 int fsaempc_debug_set_dump(double* out, int stage) { g_dump = out; g_dump_stage = stage; return 0; }
-int fsaempc_debug_set_polished(int* out) { g_polished = out; return 0; }
 
 int fsaempc_qp_set_timing(int enable) {
   if (enable && !g_ev[0]) {

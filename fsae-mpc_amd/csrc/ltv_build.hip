@@ -30,8 +30,10 @@ DEVINL void seg_lookup(int M, double dl, double t, int& seg, double& tau) {
   double r = t - floor(t / per) * per;  // MATLAB mod()
   if (r < 0) r += per;
   if (r >= per) r -= per;
-  int i = (int)floor(r / dl);
+  int i = 0;
+  if (r >= 0 && r < per) i = (int)floor(r / dl);   // a non-finite arc length (a car whose state blew up) must not index the table
   if (i >= M) i = M - 1;
+  if (i < 0) i = 0;
   seg = i; tau = r / dl - (double)i;
 }
 DEVINL double kappa(const Spl& sp, double s) {

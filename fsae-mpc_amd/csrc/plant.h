@@ -24,3 +24,4 @@ struct ClPlantParams {
 };
 hipError_t cl_pre_launch(const ClPreParams& P, hipStream_t st);
 hipError_t cl_plant_launch(const ClPlantParams& P, hipStream_t st);
+hipError_t cl_accept_launch(int len_x, int len_u, int batch, const double* x_new, const double* u_new, const int* exitflag, double* x_keep, double* u_keep, hipStream_t st);

@@ -23,8 +23,10 @@ DEVINL void seg_lookup(int M, double dl, double t, int& seg, double& tau) {
   double r = t - floor(t / per) * per;  // MATLAB mod()
   if (r < 0) r += per;
   if (r >= per) r -= per;
-  int i = (int)floor(r / dl);
+  int i = 0;
+  if (r >= 0 && r < per) i = (int)floor(r / dl);   // a non-finite arc length (a car whose state blew up) must not index the table
   if (i >= M) i = M - 1;
+  if (i < 0) i = 0;
   seg = i; tau = r / dl - (double)i;
 }
 // value, first and second derivative of one Bezier spline at t (interpolate_spline{,_d,_dd}.m)
@@ -81,7 +83,14 @@ __global__ void cl_pre_kernel(ClPreParams P) {
   if (nx == 5) { x0[3] = sqrt(c[3] * c[3] + c[4] * c[4]); x0[4] = c[6]; }   // main.m:95
   else { x0[3] = c[3]; x0[4] = c[4]; x0[5] = c[5]; x0[6] = c[6]; }           // main.m:97
   if (s >= P.L) P.finished[b] = 1;                                           // main.m:101-104
-  if (!(fabs(s) < INFINITY)) P.finished[b] = 2;                              // frame transform lost the track (Newton diverged): the car is out
+  {   // the car is out when the frame transform lost the track (Newton diverged) or its state left every physical range
+    bool okc = fabs(s) < INFINITY && fabs(n) < 3.0 && fabs(c[3]) < 100.0 && fabs(c[4]) < 100.0;   // 3 m off a 1.5 m wide track: out of the race
+    for (int j = 0; j < 7; ++j) okc = okc && fabs(c[j]) < 1e6;
+    if (!okc) {
+      P.finished[b] = 2;
+      for (int j = 0; j < nx; ++j) x0[j] = 0.0;   // finite placeholder data for the (ignored) QP of this car
+    }
+  }
   double cum = 0.0;
   for (int k = 0; k < N; ++k) {                                              // main.m:107-114
     for (int j = 0; j < nx; ++j) xr[k * nx + j] = 0.0;
@@ -143,12 +152,15 @@ __global__ void cl_plant_kernel(ClPlantParams P) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= P.batch) return;
   if (P.finished && P.finished[b]) return;        // the reference leaves the loop when the lap is complete
-  if (P.exitflag && P.exitflag[b] != 0) return;   // no usable plan this step: hold the car (the reference would crash on NaN)
+  // The reference keeps driving on whatever plan the solver returned, whatever its exit flag (main.m:163-175); `exitflag`
+  // (optional) only holds a car when the caller asks for it with a flag < -100 (not a solver outcome).
+  if (P.exitflag && P.exitflag[b] < -100) return;
   double x[7], st[4], u[2] = {0.0, 0.0};
   for (int i = 0; i < 7; ++i) x[i] = P.cart[(size_t)b * 7 + i];
   for (int i = 0; i < 4; ++i) st[i] = P.pid[(size_t)b * 4 + i];
   const double* xo = P.x_opt + (size_t)b * P.nx * P.N;
   const double v_ref = xo[3], delta_ref = xo[P.nx - 1];     // main.m:167-168 (x_opt(4), x_opt(N_x))
+  if (!(fabs(v_ref) < INFINITY) || !(fabs(delta_ref) < INFINITY)) return;   // no finite plan at all: hold the car
   for (int j = 0; j < 10; ++j) {                             // main.m:171-175
     u[0] = pid(v_ref, x[3], 16000.0, 0.0, 0.0, 2800.0, st);
     u[1] = pid(delta_ref, x[6], 80.0, 0.0, 0.0, 0.8, st + 2);
@@ -159,8 +171,29 @@ __global__ void cl_plant_kernel(ClPlantParams P) {
   if (P.u_last) { P.u_last[(size_t)b * 2] = u[0]; P.u_last[(size_t)b * 2 + 1] = u[1]; }
 }
 
+// main.m:122-126: the plan of this step becomes the linearisation point (and the source of the set points) of the next
+// one.  The reference takes over whatever qpOASES returned; this build takes a plan over when the solve ended with exit
+// flag 0 or 1 and every entry is finite -- after an abnormal exit (-1, -2) the returned point is the last interior-point
+// iterate, which unlike an active-set iterate need not respect the actuator bounds, so the car keeps driving on its last
+// good plan instead (documented deviation).
+__global__ void cl_accept_kernel(int len_x, int len_u, int batch, const double* x_new, const double* u_new, const int* exitflag, double* x_keep, double* u_keep) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  bool ok = !exitflag || exitflag[b] == 0 || exitflag[b] == 1;
+  for (int i = 0; i < len_x; ++i) ok = ok && fabs(x_new[(size_t)b * len_x + i]) < INFINITY;
+  for (int i = 0; i < len_u; ++i) ok = ok && fabs(u_new[(size_t)b * len_u + i]) < INFINITY;
+  if (!ok) return;
+  for (int i = 0; i < len_x; ++i) x_keep[(size_t)b * len_x + i] = x_new[(size_t)b * len_x + i];
+  for (int i = 0; i < len_u; ++i) u_keep[(size_t)b * len_u + i] = u_new[(size_t)b * len_u + i];
+}
+
 }  // namespace
 
+hipError_t cl_accept_launch(int len_x, int len_u, int batch, const double* x_new, const double* u_new, const int* exitflag, double* x_keep, double* u_keep, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  hipLaunchKernelGGL(cl_accept_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, len_x, len_u, batch, x_new, u_new, exitflag, x_keep, u_keep);
+  return hipGetLastError();
+}
 hipError_t cl_pre_launch(const ClPreParams& P, hipStream_t st) {
   if (P.batch == 0) return hipSuccess;
   hipLaunchKernelGGL(cl_pre_kernel, dim3((P.batch + 63) / 64), dim3(64), 0, st, P);

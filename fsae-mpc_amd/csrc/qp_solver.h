@@ -4,7 +4,7 @@
 #include <stddef.h>
 
 #define QP_MAX_T 12
-#define QP_WG_RES_MAX_T 6      // tile counts for which the LDS-resident variant (and the 1-column border) is built
+#define QP_WG_RES_MAX_T 5      // tile counts for which the LDS-resident variant (and the 1-column border) of qp_wg.hip is built (development builds)
 #define QP_FLAG_PENDING 99
 
 struct QpDims {
@@ -33,7 +33,8 @@ struct QpParams {
   double tol, tol_loose, tol_x, inf_bound;
   int max_iter, shared_HA, polish;
   int only_pending;   // workgroup kernel, streaming variant: solve only the instances the resident variant handed over (exit flag QP_FLAG_PENDING)
-  int* polished;   // optional per-instance output: 1 if the active-set polish was accepted
+  int* polished;   // optional per-instance output: >0 if the active-set refinement was accepted (attempt count), <0 reason of rejection
+  double* kkt;     // optional per-instance output: relative KKT residual of the returned point as the kernel measured it
   double* dump; int dump_stage, dump_iter;
 };
 

@@ -96,10 +96,9 @@ template <int T> struct Tri {
   __host__ __device__ static constexpr int idx(int I, int J) { return I * T - (I * (I - 1)) / 2 + (J - I); }
 };
 
-// Translation units: the solve kernel is instantiated for T = 1..8 and three border widths; compiled in one piece
-// that is four minutes of hipcc, so the Makefile builds this file five times (-DQP_TU=0: prep kernel, dimensions,
-// dispatch, self test; -DQP_TU=1..4: one group of T each).  Without QP_TU everything lands in one object (used by the
-// one-command diagnostic builds).
+// Translation units: the solve kernel is instantiated for T = 1..5 and three border widths; the Makefile builds this
+// file three times (-DQP_TU=0: prep kernel, dimensions, dispatch, self test; -DQP_TU=1: T = 1..4; -DQP_TU=2: T = 5).
+// Without QP_TU everything lands in one object (used by the one-command diagnostic builds).
 #if !defined(QP_TU) || QP_TU == 0
 #define QP_MAIN_TU 1
 #else
@@ -360,25 +359,30 @@ template <int C> struct IC { static constexpr int value = C; };
 // ---------------------------------------------------------------------------------------------
 // Operand stream of the three passes over A~.  The stream is a plain sequence of 1 KB records (one column tile of
 // one pair of k-steps) in exactly the order the passes consume it, so the producer is a linear walk: records go
-// global memory -> LDS by `global_load_lds_dwordx4` (no VGPRs involved, LDS address = M0 + lane*16) into a ring of R
-// records, always D records ahead of the consumer, whatever the tile count of the current trip is.  The consumer
-// reads a record with one ds_read_b128 per lane.  The compiler does not track LDS-DMA -> ds_read dependences, so the
-// ordering is explicit: after topping the lead up to D records beyond the ones about to be consumed,
-// `s_waitcnt vmcnt(D)` guarantees that everything older than the newest D vector-memory operations has landed (any
-// other load or store in between only makes the wait more conservative); the asm memory clobbers keep the compiler
-// from moving LDS reads or DMA issues across the wait.  The ring is drained (vmcnt(0)) before a pass returns.
+// global memory -> LDS by `global_load_lds_dwordx4` (no VGPRs involved, LDS address = M0 + lane*16) into a ring of two
+// halves of T records: the pair of k-steps being consumed and the pair in flight.  The consumer reads a record with
+// one ds_read_b128 per lane.  The compiler does not track LDS-DMA -> ds_read dependences, so the ordering is explicit,
+// and it is a FULL drain: `s_waitcnt vmcnt(0)` at the top of a pair (every vector-memory operation of this wave has
+// completed, hence this pair's records are in LDS), then the DMA of the next pair is issued and flies during the
+// matrix-core work of this one.
+//   Round 1 kept D records in flight and waited with `s_waitcnt vmcnt(D)`.  That is only sound if vector-memory
+//   operations retire in issue order, and on gfx9 loads and stores do not retire in order RELATIVE TO EACH OTHER (loads
+//   among themselves do, stores among themselves do; LLVM's SIInsertWaitcnts treats mixed pending loads and stores as an
+//   out-of-order counter for exactly this reason).  A store issued inside the window -- a register spill of the
+//   accumulators, a row-array store of the pass -- can retire before an older LDS-DMA load, vmcnt drops to D, and the
+//   consumer reads a ring slot whose record has not landed: an iterate that is "slightly wrong", depending on where the
+//   register allocator happened to put its spill code.  That was the build-variant fragility of round 1.
+// The asm memory clobbers keep the compiler from moving LDS reads or DMA issues across the wait.
 // ---------------------------------------------------------------------------------------------
+#ifdef QP_OLD_STREAM   // bisecting experiment: the round-1 ring (D records in flight, counted vmcnt)
 template <int T> struct StreamCfg {
-  static constexpr int D = T <= 5 ? 6 : (T == 6 ? 4 : (T == 7 ? 3 : 2));   // records in flight beyond the current pair of k-steps
-  static constexpr int R = D + T;                                          // ring capacity
+  static constexpr int D = T <= 5 ? 6 : (T == 6 ? 4 : (T == 7 ? 3 : 2));
+  static constexpr int R = D + T;
 };
-#define QP_STR2(x) #x
-#define QP_STR(x) QP_STR2(x)
 template <int T> struct Stream {
   static constexpr int D = StreamCfg<T>::D, R = StreamCfg<T>::R;
-  const char* gnext;   // wave-uniform: global address of the next record to issue
-  int slot_i, slot_e;  // ring slot of the next record to issue / to consume
-  DEVINL void start(const Ctx& k) {
+  const char* gnext; int slot_i, slot_e;
+  DEVINL void start(const Ctx& k, int) {
     gnext = reinterpret_cast<const char*>(k.Aw); slot_i = 0; slot_e = 0;
 #pragma unroll
     for (int j = 0; j < D; ++j) issue(k);
@@ -389,8 +393,7 @@ template <int T> struct Stream {
     gnext += 1024;
     slot_i = slot_i + 1 == R ? 0 : slot_i + 1;
   }
-  // tops the lead up by C records, waits for the C records of the current pair of k-steps and reads them
-  template <int C> DEVINL void next_pair(const Ctx& k, v2d* b) {
+  template <int C> DEVINL void next_pair(const Ctx& k, v2d* b, int) {
 #pragma unroll
     for (int t = 0; t < C; ++t) issue(k);
     if (D == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -406,6 +409,41 @@ template <int T> struct Stream {
   }
   DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
+#else
+template <int T> struct StreamCfg {
+  static constexpr int R = 2 * T;   // ring capacity: two pairs of k-steps
+};
+template <int T> struct Stream {
+  static constexpr int R = StreamCfg<T>::R;
+  const char* gnext;   // wave-uniform: global address of the next record to issue
+  int half;            // ring half that holds the pair to consume next
+  DEVINL void issue(const Ctx& k, int slot) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gnext + k.lane * 16),
+                                     (__attribute__((address_space(3))) void*)(k.ring + slot * 128), 16, 0, 0);
+    gnext += 1024;
+  }
+  DEVINL void start(const Ctx& k, int c0) {   // c0: tile count of the first pair
+    gnext = reinterpret_cast<const char*>(k.Aw); half = 0;
+
+#pragma unroll
+    for (int t = 0; t < T; ++t) if (t < c0) issue(k, t);
+  }
+  // waits for the C records of the current pair, issues the cn records of the pair after it (0 at the end of the stream)
+  // into the other half and reads the current pair
+  template <int C> DEVINL void next_pair(const Ctx& k, v2d* b, int cn) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int other = (half ^ 1) * T;
+#pragma unroll
+    for (int t = 0; t < T; ++t) if (t < cn) issue(k, other + t);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < C; ++t) b[t] = *reinterpret_cast<const v2d*>(k.ring + (half * T + t) * 128 + k.lane * 2);
+    half ^= 1;
+  }
+  DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+
+#endif
 
 // Per-row coefficients of a pass (owner layout [slot][64] in global memory): one slot (16 k-steps) at a time is staged
 // in LDS -- NA wave-wide loads per 16 k-steps instead of NA broadcast loads per k-step -- and read back as 16-byte
@@ -454,7 +492,7 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
   Stream<T> st;
   CoefStage<NA> cs;
   int tr = 0;
-  if (k.ntr > 0) { st.start(k); cs.load(k, arr, 0); }
+  if (k.ntr > 0) { st.start(k, k.tcs[0]); cs.load(k, arr, 0); }
   auto phase = [&](auto Cc) __attribute__((always_inline)) {
     constexpr int C = decltype(Cc)::value;
     const int tr_end = k.tend[C];
@@ -463,7 +501,7 @@ template <int T, int NB> DEVINL void pass_syrk(const Ctx& k, v4d* acc, double* P
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         v2d b[C], cf[NA];
-        st.template next_pair<C>(k, b);
+        st.template next_pair<C>(k, b, u == 0 ? C : (tr + 1 < tr_end ? C : (tr + 1 < k.ntr ? k.tcs[tr + 1] : 0)));
         cs.read_pair(k, 4 * tr + 2 * u, cf);
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -560,7 +598,7 @@ template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, c
   Stream<T> st;
   CoefStage<NA> cs;
   int tr = 0;
-  if (k.ntr > 0) { st.start(k); if (NA > 0) cs.load(k, arr, 0); }
+  if (k.ntr > 0) { st.start(k, k.tcs[0]); if (NA > 0) cs.load(k, arr, 0); }
   auto phase = [&](auto Cc) __attribute__((always_inline)) {
     constexpr int C = decltype(Cc)::value;
     const int tr_end = k.tend[C];
@@ -569,7 +607,7 @@ template <int T, int NB, int NVEC, int FUSE> DEVINL void pass_Av(const Ctx& k, c
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         v2d b[C], cf[NA > 0 ? NA : 1];
-        st.template next_pair<C>(k, b);
+        st.template next_pair<C>(k, b, u == 0 ? C : (tr + 1 < tr_end ? C : (tr + 1 < k.ntr ? k.tcs[tr + 1] : 0)));
         if (NA > 0) cs.read_pair(k, 4 * tr + 2 * u, cf);
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -975,7 +1013,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 
   STAMP_DECL
   int flag = 1, it = 0, flag_polished = 0;
-  double fval_s = 0.0;
+  double fval_s = 0.0, merit_s = INFINITY;   // objective / relative KKT residual of the point that is returned
   if (infeas) { flag = -2; }
 
   // ---- v = G x ----
@@ -1122,6 +1160,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }
     const double dmax = wave_max(dmax_l);
     WAVE_SYNC();
+#ifdef QP_DEBUG_DUMP   // diagnostic build only (libfsaempc_dbg.so): the shipped kernel carries no dump branches
     if (P.dump && b == 0 && P.dump_stage == 1 && it_now == P.dump_iter) {  // debug: M, p1, p2, p3, Hx
 #pragma unroll
       for (int I = 0; I < T; ++I)
@@ -1136,6 +1175,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         for (int i = lane; i < n; i += 64) { P.dump[i * n + nc + e] = MB[e * k.np + i]; P.dump[(nc + e) * n + i] = MB[e * k.np + i]; }
       for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
     }
+#endif
     {
       const double* vin[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
       rhs_load<T, 2 + NB>(k, rh, vin);
@@ -1235,7 +1275,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     const double rd_rel = wave_max(m_rd);
     const double gap_rel = gap / fmax(1.0, fabs(fval));
     const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
-    fval_s = fval;
+    fval_s = fval; merit_s = merit;
     const bool res_ok = merit <= P.tol;
     if (!(merit < INFINITY)) { flag = have_saved ? 2 : -1; break; }
     if (merit <= P.tol_loose && merit < saved_merit) {
@@ -1291,9 +1331,11 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       break;
     }
     STAMP(6);
+#ifdef QP_DEBUG_DUMP
     if (P.dump && b == 0 && P.dump_stage == 2 && it == P.dump_iter) {
       for (int i = lane; i < n; i += 64) { P.dump[i] = R1[i]; P.dump[n + i] = R2[i]; }
     }
+#endif
     if (res_ok) {  // Newton-decrement test in the caller's coordinates
       double dm = 0, xm = 1.0;
       for (int h = 0; h < 2; ++h) {
@@ -1425,7 +1467,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const double a_h = (-bp + mufull / (bd + amax_w * bdd)) / bdp;
       alpha = fmin(1.0, fmin(0.99999999 * amax_w, fmax(a_h, gamma_f * amax_w)));
     }
-#ifndef QP_NO_DBG4
+#ifdef QP_DEBUG_DUMP
     if (P.dump && b == 0 && P.dump_stage == 4 && it == P.dump_iter) {   // debug: step-length pipeline of this iteration
       double c1 = 0, c2 = 0, c3 = 0, c4 = 0;
       for (int js = 0; js < JT; ++js) { const int ix = js * 64 + lane; c1 += aVA[ix]; c2 += aVC[ix]; c3 += aW2[ix]; c4 += aW1[ix]; }
@@ -1480,7 +1522,10 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     WAVE_SYNC();
     STAMP(12);
     // divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47)
-    if (xn > 1e13) { flag = -3; break; }
+    // a diverging iterate is 'unbounded' (-3) only if it is primal feasible and the objective follows it to -infinity;
+    // with a primal residual it is the signature of an infeasible QP (-2); on a bounded feasible problem (every LTV-MPC QP:
+    // boxed inputs, slacks with positive linear cost) it is an internal failure (-1)
+    if (xn > 1e13) { flag = rp_prev > 1e-6 ? -2 : (fval < -1e13 ? -3 : -1); break; }
     if (zn > 1e15 && rp_prev > 1e-6) { flag = -2; break; }
     // once an iterate met tol_loose, a handful of non-improving iterations means the end game lost its numerical
     // footing: return the saved iterate (this also bounds the iteration tail, i.e. the kernel's drain time)
@@ -1488,13 +1533,15 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   }
 
   // ---- outputs ----
-  const bool v_current = flag == 0 || flag == 4;   // aV still equals G x and fval_s is the objective at x (not so after a restore)
+  // The last iterate (or the best saved one) is returned whatever the exit code: the reference keeps driving on whatever the
+  // solver handed back (main.m:163-175).
+  const bool v_current = flag == 0 || flag == 4;   // aV still equals G x and fval_s is the objective at x (not so after a restore / an update)
   if (flag == 2) {  // restore the best iterate that met tol_loose
     for (int i = lane; i < k.np; i += 64) X[i] = XS[i];
     for (int js = 0; js < JT; ++js) aW3[js * 64 + lane] = LAMS[js * 64 + lane];
-    flag = 0;
+    flag = 0; merit_s = saved_merit;
     WAVE_SYNC();
-  } else if (flag == 0 || flag == 1 || flag == 4) {
+  } else {
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
       const bool valid = row_valid(k, js);
@@ -1513,7 +1560,11 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   // could not (rejected 10-20 % of the instances).  One fused stream over A~ per CG step (q = A_W w and A_W'q together),
   // A'p kept by recurrence.  The result is accepted only if a fresh evaluation says it is a KKT point of the full QP;
   // otherwise the interior-point iterate is returned.
+#ifdef QP_NO_NEWPOLISH
+  if (false) {
+#else
   if ((flag == 0 || flag == 4) && P.polish) {
+#endif
     const double rho = 1e6, pin = 1e16, rinv = 1.0 / rho;
     double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
     double* PC = rowp(k, R_RPU); double* PP = rowp(k, R_CC2); double* PZ0 = aW2;   // constraint residual c, CG direction p, zeros
@@ -1747,7 +1798,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
           aW3[ix] = sd > 0 ? fmax(y, 0.0) : (sd < 0 ? fmin(y, 0.0) : 0.0);
         }
         flag_polished = 1 + attempt;
-        fval_s = f2;
+        fval_s = f2; merit_s = fmax(m_rd, fmax(m_rp, m_cp / fmax(1.0, fabs(f2))));
         flag = 0;
       }
       WAVE_SYNC();
@@ -1755,21 +1806,20 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }   // attempts
   }
   if (flag == 4) flag = -1;   // not certified
-  const bool have_x = flag == 0 || flag == 1;
   double* xo = P.x + (size_t)b * n;
-  for (int i = lane; i < n; i += 64) xo[i] = have_x ? X[i] * EV[i] : NAN;
+  for (int i = lane; i < n; i += 64) xo[i] = X[i] * EV[i];
   if (P.lambda) {
     double* lo = P.lambda + (size_t)b * (n + k.m);
     for (int jb = 0; jb < k.JB; ++jb) {
       const int i = jb * 64 + lane;
-      if (i < n) lo[i] = have_x ? aW3[(J + jb) * 64 + lane] / EV[i] : NAN;
+      if (i < n) lo[i] = aW3[(J + jb) * 64 + lane] / EV[i];
     }
     for (int js = 0; js < J; ++js) {
       const int r = k.perm[js * 64 + lane];   // original row of this sorted position
-      if (r >= 0) lo[n + r] = have_x ? aW3[js * 64 + lane] * Fs[js * 64 + lane] : NAN;
+      if (r >= 0) lo[n + r] = aW3[js * 64 + lane] * Fs[js * 64 + lane];
     }
   }
-  if (have_x && !v_current) {  // objective at the restored point, in the caller's units (H~,g~ scaling is objective preserving)
+  if (!(v_current || flag_polished > 0)) {  // objective at the returned point, in the caller's units (H~,g~ scaling is objective preserving)
     WAVE_SYNC();
     hx_full(X);
     WAVE_SYNC();
@@ -1780,10 +1830,11 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   STAMP(13);
   STAMP_OUT;
   if (lane == 0) {
-    P.fval[b] = have_x ? fval_s : NAN;
+    P.fval[b] = fval_s;
     P.exitflag[b] = flag;
     P.iter[b] = it;
     if (P.polished) P.polished[b] = flag_polished;
+    if (P.kkt) P.kkt[b] = merit_s;
   }
 }
 
@@ -1967,8 +2018,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
   {
-    const int Tt = d->T, Dd = Tt <= 5 ? 6 : (Tt == 6 ? 4 : (Tt == 7 ? 3 : 2));   // = StreamCfg<T>::D
-    d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272 + (size_t)(Dd + Tt) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);
+    d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272 + (size_t)(2 * d->T + 2) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);   // ring = StreamCfg<T>::R records (+2 spare)
   }
   {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP.  The operand stream of A~ stays resident in LDS when
       // ~2/3 of its dense size fits (structurally empty tiles are skipped, the LTV-MPC families keep ~60 %) and the rows
@@ -1979,10 +2029,15 @@ void qp_make_dims(int n, int m, QpDims* d) {
     d->NBk = d->nb == 0 ? 0 : ((d->nb == 1 && d->T <= QP_WG_RES_MAX_T) ? 1 : 4);
     d->lds_aw_bytes = 0;
     const size_t base = qp_wg_lds_base_bytes(*d, d->W, d->NBk, true);
+#ifdef QP_WG_ONE_TU   // the LDS-resident variant exists in development builds only
     if (base < cap && d->T <= QP_WG_RES_MAX_T && d->J + d->JB <= 8 && dense > 0) {
       const size_t avail = (cap - base) & ~(size_t)1023;
       if (dense * 2 / 3 <= avail) d->lds_aw_bytes = dense < avail ? dense : avail;
     }
+#else
+    (void)cap; (void)dense; (void)base;
+    if (d->NBk == 1) d->NBk = 4;
+#endif
     d->lds_wg = d->lds_aw_bytes ? base + d->lds_aw_bytes : qp_wg_lds_base_bytes(*d, d->W, d->NBk, false);
     if (const char* ex = getenv("FSAEMPC_WG")) {   // development only (QP_WG_EXPERIMENT builds): "W,RES"
       int Wx = 8, Rx = 1;
@@ -2013,12 +2068,9 @@ template <int T, int NB> static hipError_t launch_solve_TN(const QpParams& P, in
   return hipGetLastError();
 }
 template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, hipStream_t st) {
-  switch (P.d.NB) {
-    case 0: return launch_solve_TN<T, 0>(P, batch, st);
-#ifndef QP_NO_BORDER
+  switch (P.d.NB) {   // bordered shapes only (nV mod 16 in 1..4: every LTV-MPC horizon N = 8k); the rest runs on qp_wg.hip
     case 1: return launch_solve_TN<T, 1>(P, batch, st);
     case 4: return launch_solve_TN<T, 4>(P, batch, st);
-#endif
     default: return hipErrorInvalidValue;
   }
 }
@@ -2026,8 +2078,6 @@ template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, 
 #if defined(QP_TU)
 hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st);
-hipError_t qp_launch_solve_g3(const QpParams& P, int batch, hipStream_t st);
-hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st);
 #if QP_TU == 1
 hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st) {
   switch (P.d.T) {
@@ -2040,28 +2090,37 @@ hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st) {
 }
 #elif QP_TU == 2
 hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<5>(P, batch, st); }
-#elif QP_TU == 3
-hipError_t qp_launch_solve_g3(const QpParams& P, int batch, hipStream_t st) {
-  return P.d.T == 6 ? launch_solve_T<6>(P, batch, st) : launch_solve_TN<8, 0>(P, batch, st);
-}
-#elif QP_TU == 4
-hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<7>(P, batch, st); }
 #endif
 #endif
 
 #if QP_MAIN_TU
-// qp_wg.hip (workgroup-per-QP kernel) serves the tile counts the one-wavefront kernel cannot hold in registers
-// (T = 9..12, nV up to 196): built as two translation units named by their first T.  A development build
-// (-DQP_WG_ONE_TU, `make devlib`) has its own selection of tile counts in one unit and FSAEMPC_QP_WG=1 routes every shape to it.
+// Kernel selection.  The one-wavefront kernel of this file serves the bordered shapes up to T = 5 column tiles
+// (nV = 16T + 1..4 <= 84: the LTV-MPC QPs of the horizons N = 8k <= 40, i.e. the headline shapes).  Its other
+// instantiations are retired: T >= 5 without border and T = 6..8 computed wrong iterates in some -O2/-O3 builds of a source
+// whose -O1 build is right -- deterministic, but moving with unrelated edits (compiling the dump hooks out was enough);
+// DESIGN.md, "Build-variant fragility", lists what was ruled out.  qp_wg.hip (workgroup-per-QP kernel: no inline
+// assembly, no LDS-DMA, accumulators spread over eight wavefronts, ~40 % of the registers) serves everything else
+// (T = 1..12, nV up to 196), built as five translation units named by their first T.  The -O1 guard
+// (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build) compares every instantiation of both kernels with
+// an -O1 build on the GPU.  A development build (-DQP_WG_ONE_TU, `make devlib`) has its own selection of tile counts in one
+// unit and FSAEMPC_QP_WG=1 routes every shape to it.
+#define QP_V1_MAX_T 5
 #ifdef QP_WG_ONE_TU
 hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
 static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) { return qp_wg_launch_1(P, batch, st); }
 #else
+hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_6(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_7(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_9(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_11(const QpParams& P, int batch, hipStream_t st);
 static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) {
-  if (P.d.T >= 9 && P.d.T <= 10) return qp_wg_launch_9(P, batch, st);
-  if (P.d.T >= 11 && P.d.T <= 12) return qp_wg_launch_11(P, batch, st);
+  const int T = P.d.T;
+  if (T <= 5) return qp_wg_launch_1(P, batch, st);
+  if (T == 6) return qp_wg_launch_6(P, batch, st);
+  if (T == 7 || T == 8) return qp_wg_launch_7(P, batch, st);
+  if (T == 9 || T == 10) return qp_wg_launch_9(P, batch, st);
+  if (T == 11 || T == 12) return qp_wg_launch_11(P, batch, st);
   return hipErrorInvalidValue;
 }
 #endif
@@ -2087,14 +2146,11 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
 #endif
   {
     static const bool force_wg = getenv("FSAEMPC_QP_WG") != nullptr;   // development builds only
-    if (P.d.T > 8 || force_wg) return qp_wg_launch(P, batch, st);
+    if (P.d.T > QP_V1_MAX_T || P.d.nb == 0 || force_wg) return qp_wg_launch(P, batch, st);
   }
 #if !defined(QP_TU)
   switch (P.d.T) {
-#if defined(QP_O1_GUARD)
-    case 5: return launch_solve_T<5>(P, batch, st);
-    case 8: return launch_solve_TN<8, 0>(P, batch, st);
-#elif defined(QP_ONLY_T)
+#if defined(QP_ONLY_T)
     case QP_ONLY_T: return launch_solve_T<QP_ONLY_T>(P, batch, st);
 #else
     case 1: return launch_solve_T<1>(P, batch, st);
@@ -2102,9 +2158,6 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     case 3: return launch_solve_T<3>(P, batch, st);
     case 4: return launch_solve_T<4>(P, batch, st);
     case 5: return launch_solve_T<5>(P, batch, st);
-    case 6: return launch_solve_T<6>(P, batch, st);
-    case 7: return launch_solve_T<7>(P, batch, st);
-    case 8: return launch_solve_TN<8, 0>(P, batch, st);
 #endif
     default: return hipErrorInvalidValue;
   }
@@ -2112,8 +2165,6 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   switch (P.d.T) {
     case 1: case 2: case 3: case 4: return qp_launch_solve_g1(P, batch, st);
     case 5: return qp_launch_solve_g2(P, batch, st);
-    case 6: case 8: return qp_launch_solve_g3(P, batch, st);
-    case 7: return qp_launch_solve_g4(P, batch, st);
     default: return hipErrorInvalidValue;
   }
 #endif

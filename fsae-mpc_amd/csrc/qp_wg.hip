@@ -328,7 +328,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   red_next();
 
   int flag = 1, it = 0, flag_polished = 0;
-  double fval_s = 0.0;
+  double fval_s = 0.0, merit_s = INFINITY;   // objective / relative KKT residual of the point that is returned
   if (infeas) flag = -2;
   STAMP_DECL
 
@@ -925,7 +925,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     const double rd_rel = wave_max(m_rd);
     const double gap_rel = gap / fmax(1.0, fabs(fval));
     const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
-    fval_s = fval;
+    fval_s = fval; merit_s = merit;
     const bool res_ok = merit <= P.tol;
     if (!(merit < INFINITY)) { flag = have_saved ? 2 : -1; break; }
     if (merit <= P.tol_loose && merit < saved_merit) {
@@ -1219,7 +1219,9 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     red_next();
     STAMP(13);
     // divergence heuristics -> qpOASES exit codes (qpOASES.m:43-47)
-    if (xn > 1e13) { flag = -3; break; }
+    // a diverging iterate is 'unbounded' (-3) only if it is primal feasible and the objective follows it to -infinity; with a
+    // primal residual it is the signature of an infeasible QP (-2); otherwise an internal failure (-1)
+    if (xn > 1e13) { flag = rp_prev > 1e-6 ? -2 : (fval < -1e13 ? -3 : -1); break; }
     if (zn > 1e15 && rp_prev > 1e-6) { flag = -2; break; }
     if (stall > (have_saved ? 5 : 25)) { flag = have_saved ? 2 : (rp_prev > 1e-6 ? -2 : 1); break; }
   }
@@ -1233,11 +1235,11 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     for (int i = tid; i < np; i += NTH) X_(i) = XS[i];
 #pragma unroll
     for (int si = 0; si < SW; ++si) { const int js = w + W * si; if (js < JT) lam_out[si] = LAMS[js * 64 + lane]; }
-    flag = 0;
+    flag = 0; merit_s = saved_merit;
   }
   __syncthreads();
-  if (flag == 4) flag = -1;   // not certified (the active-set refinement lives in a later revision of this kernel)
-  const bool have_x = flag == 0 || flag == 1;
+  if (flag == 4) flag = -1;   // not certified (this kernel has no active-set refinement yet)
+  const bool have_x = true;   // the last iterate is returned whatever the exit code (main.m:163-175 keeps driving on it)
   double* xo = P.x + (size_t)b * n;
   for (int i = tid; i < n; i += NTH) xo[i] = have_x ? X_(i) * EV_(i) : NAN;
   if (P.lambda) {
@@ -1268,6 +1270,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     P.exitflag[b] = flag;
     P.iter[b] = it;
     if (P.polished) P.polished[b] = flag_polished;
+    if (P.kkt) P.kkt[b] = merit_s;
   }
 }
 
@@ -1297,6 +1300,7 @@ template <int T, int NB> static hipError_t launch_stream(const QpParams& P, int 
 // resident kernel (when the host reserved LDS for the stream; JT <= 8) followed by the streaming kernel for the leftovers
 template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P0, int batch, hipStream_t st) {
   QpParams P = P0;
+#ifdef QP_WG_DEV
   if constexpr (T <= QP_WG_RES_MAX_T) {
     if (P.d.lds_aw_bytes > 0 && P.d.J + P.d.JB <= 8) {
       P.only_pending = 0;
@@ -1310,6 +1314,7 @@ template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P0, int b
       return launch_stream<T, NB>(P, batch, st);
     }
   }
+#endif
   P.only_pending = 0;
   return launch_stream<T, NB>(P, batch, st);
 }
@@ -1323,11 +1328,14 @@ template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P0, int b
 template <int T> static hipError_t launch_wg_sel(const QpParams& P, int batch, hipStream_t st) {
   if constexpr (T >= QP_WG_TLO && T <= QP_WG_THI) {
     if (P.d.T == T) {
-#ifndef QP_WG_DEV   // development builds: only the bordered shapes
-      if (P.d.NBk == 0) return launch_wg_T<T, 0>(P, batch, st);
-#endif
+#ifdef QP_WG_DEV    // development builds: the bordered headline shapes, every variant
       if constexpr (T <= QP_WG_RES_MAX_T) { if (P.d.NBk == 1) return launch_wg_T<T, 1>(P, batch, st); }
       return launch_wg_T<T, 4>(P, batch, st);
+#else               // product: bordered shapes up to T = 5 run on the one-wavefront kernel (qp_solver.hip)
+      if (P.d.NBk == 0) return launch_wg_T<T, 0>(P, batch, st);
+      if constexpr (T > 5) return launch_wg_T<T, 4>(P, batch, st);
+      return hipErrorInvalidValue;
+#endif
     }
   }
   if constexpr (T < QP_MAX_T) return launch_wg_sel<T + 1>(P, batch, st);

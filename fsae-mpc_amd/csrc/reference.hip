@@ -25,7 +25,8 @@ __global__ void obtain_reference_kernel(RefParams P) {
   double* xr = P.x_ref + (size_t)b * 7 * Nt;
   // idx is kept 0-based here (MATLAB idx-1); rto as in the reference
   const double pos = mod_floor(s0, L) / ds;                      // obtain_reference.m:21-22
-  int idx = (int)floor(pos);
+  int idx = (pos >= 0 && pos < (double)Ns) ? (int)floor(pos) : 0;   // a non-finite s0 must not index the plan
+  if (idx >= Ns) idx = Ns - 1;
   double rto = mod_floor(pos, 1.0);
   const int idx1 = idx; const double rto1 = rto;
   for (int i = 0; i < Nt; ++i) {                                  // obtain_reference.m:24-35

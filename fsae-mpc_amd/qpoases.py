@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import QpDesc, check, default_opts, lib
+from ._lib import QpAux, QpDesc, check, default_opts, lib
 
 
 def _col(a, n, name):
@@ -78,10 +78,11 @@ def qpOASES(H, g, *args, options=None):
 
 
 def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=False, workspace=None, stream=None,
-                          shared_HA=False):
+                          shared_HA=False, want_aux=False):
     """Device-resident batched solve on torch CUDA(HIP) tensors (instance-major, each instance column-major):
     H (B,nV,nV), g (B,nV), A (B,nV,nC) [memory of a column-major nC x nV matrix], lb/ub (B,nV), lbA/ubA (B,nC).
-    Asynchronous on `stream` (default: torch's current stream).  Returns dict of device tensors."""
+    Asynchronous on `stream` (default: torch's current stream).  Returns dict of device tensors; want_aux adds `kkt`
+    (relative KKT residual of the returned point) and `polished` (> 0: the active-set refinement reached the vertex)."""
     import torch
     B, nV = g.shape
     nC = lbA.shape[1] if lbA is not None else 0
@@ -103,11 +104,14 @@ def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=F
     opts = options if options is not None else default_opts()
     st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
     P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    rc = lib().fsaempc_qp_solve_batch_device(C.byref(desc), P(H), P(g), P(A), P(lb), P(ub), P(lbA), P(ubA), C.byref(opts),
-                                             P(x), P(fval), P(flag), P(it), P(lam), P(workspace),
-                                             C.c_longlong(workspace.numel() * 8), C.c_void_p(st))
-    check(rc, "fsaempc_qp_solve_batch_device")
-    return dict(x=x, fval=fval, exitflag=flag, iter=it, lam=lam, workspace=workspace)
+    kkt = torch.empty(B, dtype=torch.float64, device=dev) if want_aux else None
+    pol = torch.empty(B, dtype=torch.int32, device=dev) if want_aux else None
+    aux = QpAux(P(kkt), P(pol))   # per-instance diagnostics (the analogue of qpOASES' auxOutput)
+    rc = lib().fsaempc_qp_solve_batch_device_aux(C.byref(desc), P(H), P(g), P(A), P(lb), P(ub), P(lbA), P(ubA), C.byref(opts),
+                                                 P(x), P(fval), P(flag), P(it), P(lam), C.byref(aux), P(workspace),
+                                                 C.c_longlong(workspace.numel() * 8), C.c_void_p(st))
+    check(rc, "fsaempc_qp_solve_batch_device_aux")
+    return dict(x=x, fval=fval, exitflag=flag, iter=it, lam=lam, workspace=workspace, kkt=kkt, polished=pol)
 
 
 def qpOASES_sequence(cmd, *args, options=None):

@@ -12,7 +12,9 @@
  * errors -- the analogue of the MEX gateway's mexErrMsgTxt, never a solver outcome).
  * Solver outcomes are per-instance exit flags with qpOASES semantics
  * (optimizers/matlab/qpOASES/qpOASES.m:43-47): 0 solved, 1 iteration limit,
- * -1 internal error, -2 infeasible, -3 unbounded.
+ * -1 internal error, -2 infeasible, -3 unbounded.  Whatever the flag, x / fval / lambda carry the last iterate
+ * (NaN only where the data already held one): the reference's loop keeps driving on what the solver returned
+ * (main.m:163-175).  -3 is returned only when the objective follows a diverging iterate to -infinity.
  */
 #ifndef FSAEMPC_H
 #define FSAEMPC_H
@@ -77,6 +79,26 @@ int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc,
                                   const fsaempc_qp_opts* opts,
                                   double* x, double* fval, int* exitflag, int* iter, double* lambda,
                                   void* workspace, long long workspace_bytes, void* stream);
+
+/* Optional per-instance diagnostics of a batched solve -- the analogue of qpOASES' sixth output `auxOutput`
+ * (optimizers/matlab/qpOASES/qpOASES.m:55-62).  Device arrays of `batch` entries, each may be NULL.
+ *   kkt:      relative KKT residual (max of stationarity, primal feasibility, complementarity) of the returned point as
+ *             the solver measured it.  Exit flag 0 covers both iterates converged to opts->tol and the fall-back iterate
+ *             that met opts->tol_loose; this value tells them apart.
+ *   polished: > 0 the active-set refinement was accepted (the returned point is the vertex, value = attempts used),
+ *             0 not attempted, < 0 rejected (the interior-point iterate is returned). */
+typedef struct {
+  double* kkt;
+  int* polished;
+} fsaempc_qp_aux;
+
+int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc,
+                                      const double* H, const double* g, const double* A,
+                                      const double* lb, const double* ub, const double* lbA, const double* ubA,
+                                      const fsaempc_qp_opts* opts,
+                                      double* x, double* fval, int* exitflag, int* iter, double* lambda,
+                                      const fsaempc_qp_aux* aux,
+                                      void* workspace, long long workspace_bytes, void* stream);
 
 /* Same call on host pointers: copies to the device, solves, copies back, synchronises.
  * This is what a MEX gateway calls (mex/qpOASES.cpp); validates like the original gateway
@@ -201,24 +223,36 @@ int fsaempc_cl_pre_batch_device(int model, int N, double dt, double target_vel, 
  * sub-steps of pid_controller (vehicle_models/pid_controller.m; gains main.m:84-88) + integrate_cart_dyn(x, u, dt/10)
  * (vehicle_models/cartesian_dynamic/integrate_cart_dyn.m, f_cart_dyn.m).  cart (batch x 7) and pid (batch x 4:
  * velocity integral / last error, steering integral / last error) are updated in place; cars with finished[b] != 0 or
- * exitflag[b] != 0 keep their state (both arrays optional); u_last (optional, batch x 2) = last actuator rates.
+ * a non-finite set point keep their state; exitflag (optional) holds a car only for values < -100 (a caller's own marker,
+ * never a solver outcome: the reference drives on whatever the solver returned, main.m:163-175); u_last (optional,
+ * batch x 2) = last actuator rates.
  */
 int fsaempc_cl_plant_batch_device(int model, int N, double dt, int batch, double* cart, double* pid, const double* x_opt,
                                   const int* finished, const int* exitflag, double* u_last, void* stream);
+
+/*
+ * Replaces the hand-over of main.m:122-126 per car: this step's plan (x_new: nx*N, u_new: 2*N) becomes the linearisation
+ * point and set-point source of the next step (x_keep, u_keep) when the solve ended with exit flag 0 or 1 (exitflag may
+ * be NULL: every finite plan is taken) and the plan is finite; otherwise the car keeps its last good plan and keeps
+ * driving on it.  (The reference takes over whatever qpOASES returned; the last iterate of an interior-point method
+ * after an abnormal exit need not respect the actuator bounds, hence the deviation.)
+ */
+int fsaempc_cl_accept_batch_device(int model, int N, int batch, const double* x_new, const double* u_new, const int* exitflag,
+                                   double* x_keep, double* u_keep, void* stream);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 const char* fsaempc_last_error(void);
 /* Runs the on-device fp64 MFMA layout self-test (v_mfma_f64_16x16x4_f64 operand / accumulator
  * lane maps the kernels rely on).  Returns 0 if the hardware matches, >0 number of mismatches. */
 int fsaempc_selftest_mfma(void);
-/* Debug hook used by the parity tests: dumps solver internals of instance 0 after `stage`
- * (see qp_solver.hip) into `out` (device pointer, >= 4*nV*nV+8*(nV+nC) doubles). */
+/* Debug hook of the diagnostic builds only (libfsaempc_dbg.so, -DQP_DEBUG_DUMP; the shipped kernels carry no dump
+ * branches and ignore it): dumps solver internals of instance 0 after `stage` (see qp_solver.hip) into `out` (device
+ * pointer, >= 4*nV*nV+8*(nV+nC) doubles).  Process-global, not thread-safe. */
 int fsaempc_debug_set_dump(double* out, int stage);
-/* Debug hook: per-instance int array (device, >= batch) that receives 1 where the active-set polish was accepted. */
-int fsaempc_debug_set_polished(int* out);
 
 /* Kernel timing with HIP events recorded on the launch stream of the last fsaempc_qp_solve_batch_device
- * call (prep = scaling/repack kernel, solve = interior-point kernel).  get_timing synchronises on the events. */
+ * call (prep = scaling/repack kernel, solve = interior-point kernel).  get_timing synchronises on the events.
+ * Process-global switch for benchmarks (bench.py); not thread-safe. */
 int fsaempc_qp_set_timing(int enable);
 int fsaempc_qp_get_timing(double* prep_ms, double* solve_ms);
 

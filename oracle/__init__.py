@@ -278,6 +278,19 @@ def build_qp_batch(model, track, N, dt, x0, x_ref, x_lin, u_lin, threads=0, keep
     return out
 
 
+def qp_solve_batch_aux(H, g, A, lb, ub, lbA, ubA, opts=None, threads=0):
+    """As qp_solve_batch, plus the per-instance relative KKT residual the solver measured and the refinement flag."""
+    B, nV = g.shape
+    nC = lbA.shape[1]
+    H, g, A, lb, ub, lbA, ubA = (_f(a) for a in (H, g, A, lb, ub, lbA, ubA))
+    x = np.zeros((B, nV)); fval = np.zeros(B); flag = np.zeros(B, dtype=np.int32); it = np.zeros(B, dtype=np.int32)
+    lam = np.zeros((B, nV + nC)); kkt = np.zeros(B); pol = np.zeros(B, dtype=np.int32)
+    o = opts if opts is not None else default_opts()
+    lib().orc_qp_solve_batch_ex(nV, nC, B, _p(H), _p(g), _p(A), _p(lb), _p(ub), _p(lbA), _p(ubA), C.byref(o), _p(x), _p(fval),
+                                flag.ctypes.data_as(_ip), it.ctypes.data_as(_ip), _p(lam), _p(kkt), pol.ctypes.data_as(_ip), threads)
+    return dict(x=x, fval=fval, exitflag=flag, iter=it, lam=lam, kkt=kkt, polished=pol)
+
+
 def qp_solve_batch(H, g, A, lb, ub, lbA, ubA, opts=None, threads=0, want_lambda=True):
     """H (B,nV,nV), A (B,nV,nC) = per-QP column-major nC x nV, vectors (B,*)."""
     B, nV = g.shape

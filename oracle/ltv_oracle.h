@@ -92,6 +92,10 @@ void orc_qp_default_opts(orc_qp_opts* o);
 /* min 1/2 x'Hx + g'x  s.t. lb<=x<=ub, lbA<=Ax<=ubA   (qpOASES.m:16-23)
  * lambda has nV+nC entries, bounds first, >=0 lower side active, <=0 upper (qpOASES.m:49).
  * returns exitflag: 0 solved, 1 iteration limit, -1 internal, -2 infeasible, -3 unbounded (qpOASES.m:43-47) */
+int orc_qp_solve_ex(int nV, int nC, const double* H, const double* g, const double* A,
+                    const double* lb, const double* ub, const double* lbA, const double* ubA,
+                    const orc_qp_opts* opts, double* x, double* fval, int* iter, double* lambda,
+                    double* kkt, int* polished);
 int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double* A,
                  const double* lb, const double* ub, const double* lbA, const double* ubA,
                  const orc_qp_opts* opts, double* x, double* fval, int* iter, double* lambda);
@@ -130,6 +134,10 @@ int orc_ltv_build_qp_batch(int model, int N, double dt, const orc_spline* sp, in
                            const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
                            double* H, double* g, double* A, double* lb, double* ub, double* lbA, double* ubA,
                            double* A_bar, double* Bt, double* d_bar, double* qconst, int threads);
+int orc_qp_solve_batch_ex(int nV, int nC, int batch, const double* H, const double* g, const double* A,
+                          const double* lb, const double* ub, const double* lbA, const double* ubA,
+                          const orc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
+                          double* lambda, double* kkt, int* polished, int threads);
 int orc_qp_solve_batch(int nV, int nC, int batch, const double* H, const double* g, const double* A,
                        const double* lb, const double* ub, const double* lbA, const double* ubA,
                        const orc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,

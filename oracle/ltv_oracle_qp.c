@@ -70,31 +70,56 @@ static void chol_solve(int n, const double* L, double* b) {
   }
 }
 
-/* dense LU with partial pivoting, solves K y = r in place; returns 0 ok, 1 singular */
-static int lu_solve(int n, double* K, double* r) {
+/* dense LU with partial pivoting: factor in place (unit lower factors below the diagonal), pivot rows in piv;
+ * returns 0 ok, 1 singular */
+static int lu_factor(int n, double* K, int* piv) {
   for (int k = 0; k < n; ++k) {
     int p = k; double best = fabs(K[IDX(k, k, n)]);
     for (int i = k + 1; i < n; ++i) if (fabs(K[IDX(i, k, n)]) > best) { best = fabs(K[IDX(i, k, n)]); p = i; }
     if (best < 1e-13) return 1;
-    if (p != k) {
-      for (int j = 0; j < n; ++j) { double t = K[IDX(k, j, n)]; K[IDX(k, j, n)] = K[IDX(p, j, n)]; K[IDX(p, j, n)] = t; }
-      double t = r[k]; r[k] = r[p]; r[p] = t;
-    }
-    double piv = K[IDX(k, k, n)];
+    piv[k] = p;
+    if (p != k) for (int j = 0; j < n; ++j) { double t = K[IDX(k, j, n)]; K[IDX(k, j, n)] = K[IDX(p, j, n)]; K[IDX(p, j, n)] = t; }
+    const double pv = K[IDX(k, k, n)];
     for (int i = k + 1; i < n; ++i) {
-      double f = K[IDX(i, k, n)] / piv;
-      if (f == 0) continue;
+      const double f = K[IDX(i, k, n)] / pv;
       K[IDX(i, k, n)] = f;
+      if (f == 0) continue;
       for (int j = k + 1; j < n; ++j) K[IDX(i, j, n)] -= f * K[IDX(k, j, n)];
-      r[i] -= f * r[k];
     }
-  }
-  for (int i = n - 1; i >= 0; --i) {
-    double s = r[i];
-    for (int j = i + 1; j < n; ++j) s -= K[IDX(i, j, n)] * r[j];
-    r[i] = s / K[IDX(i, i, n)];
   }
   return 0;
+}
+static void lu_apply(int n, const double* K, const int* piv, double* r) {
+  for (int k = 0; k < n; ++k) if (piv[k] != k) { double t = r[k]; r[k] = r[piv[k]]; r[piv[k]] = t; }   /* whole rows were swapped: P first */
+  for (int k = 0; k < n; ++k) {
+    const double rk = r[k];
+    if (rk != 0) for (int i = k + 1; i < n; ++i) r[i] -= K[IDX(i, k, n)] * rk;
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double sacc = r[i];
+    for (int j = i + 1; j < n; ++j) sacc -= K[IDX(i, j, n)] * r[j];
+    r[i] = sacc / K[IDX(i, i, n)];
+  }
+}
+/* solves K y = r (K is destroyed, r overwritten) with two steps of iterative refinement against a copy of K */
+static int lu_solve(int n, double* K, double* r) {
+  double* K0 = (double*)malloc(sizeof(double) * (size_t)n * n);
+  double* r0 = (double*)malloc(sizeof(double) * n);
+  double* d = (double*)malloc(sizeof(double) * n);
+  int* piv = (int*)malloc(sizeof(int) * n);
+  memcpy(K0, K, sizeof(double) * (size_t)n * n); memcpy(r0, r, sizeof(double) * n);
+  int sing = lu_factor(n, K, piv);
+  if (!sing) {
+    lu_apply(n, K, piv, r);
+    for (int itr = 0; itr < 2; ++itr) {
+      for (int i = 0; i < n; ++i) d[i] = r0[i];
+      for (int j = 0; j < n; ++j) { const double yj = r[j]; if (yj != 0) for (int i = 0; i < n; ++i) d[i] -= K0[IDX(i, j, n)] * yj; }
+      lu_apply(n, K, piv, d);
+      for (int i = 0; i < n; ++i) r[i] += d[i];
+    }
+  }
+  free(K0); free(r0); free(d); free(piv);
+  return sing;
 }
 
 double orc_qp_kkt(int nV, int nC, const double* H, const double* g, const double* A,
@@ -178,78 +203,108 @@ static void apply_Gt(const qp_work* w, const double* y, double* out) { /* out = 
   }
 }
 
+/* Active-set refinement of the interior-point point (test oracle: a dense, exact restatement that shares no
+ * machinery with the HIP path).  Working set from the multipliers (side active iff |lambda| dominates its slack), then
+ * the equality-constrained KKT system
+ *      [ H  -G_W' ] [x]   [ -g ]
+ *      [ G_W   0  ] [y] = [ b_W ]
+ * by dense LU with partial pivoting, followed by single add / drop corrections of the working set (add the most violated
+ * inactive side, else drop the multiplier of the wrong sign) until the point is a KKT point of the full QP -- the vertex
+ * an active-set solver such as qpOASES stops at.  Returns 1 and overwrites (x, lambda) on success. */
 static int polish(int n, int m, const double* H, const double* g, const double* A,
                   const double* lb, const double* ub, const double* lbA, const double* ubA,
                   double inf_bound, double* x, double* lambda) {
-  /* active set guess from the interior-point multipliers: side active iff |lambda| dominates its slack */
-  int mt = n + m, na = 0;
+  const int mt = n + m, maxcorr = 8;
+  const double ftol = 1e-9, stol = 1e-9;
+  int* side = (int*)calloc(mt, sizeof(int));
   int* act = (int*)malloc(sizeof(int) * mt);
-  double* rhs_a = (double*)malloc(sizeof(double) * mt);
   double* v = (double*)calloc(mt, sizeof(double));
+  double* xs = (double*)malloc(sizeof(double) * n);
+  int ok = 0;
   for (int i = 0; i < n; ++i) v[i] = x[i];
   for (int j = 0; j < n; ++j) for (int r = 0; r < m; ++r) v[n + r] += A[IDX(r, j, m)] * x[j];
   for (int i = 0; i < mt; ++i) {
     double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
     double lam = lambda[i];
-    if (lam > 0 && l > -inf_bound && lam > fabs(v[i] - l)) { act[na] = i; rhs_a[na] = l; ++na; }
-    else if (lam < 0 && u < inf_bound && -lam > fabs(u - v[i])) { act[na] = i; rhs_a[na] = u; ++na; }
+    if (lam > 0 && l > -inf_bound && lam > fabs(v[i] - l)) side[i] = 1;
+    else if (lam < 0 && u < inf_bound && -lam > fabs(u - v[i])) side[i] = -1;
   }
-  int ok = 0;
-  if (na <= n) {
-    int K = n + na;
+  for (int corr = 0; corr <= maxcorr && !ok; ++corr) {
+    int na = 0;
+    for (int i = 0; i < mt; ++i) if (side[i]) act[na++] = i;
+    if (na > n) break;
+    const int K = n + na;
     double* KK = (double*)calloc((size_t)K * K, sizeof(double));
     double* r = (double*)calloc(K, sizeof(double));
     for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) KK[IDX(i, j, K)] = H[IDX(i, j, n)];
     for (int a = 0; a < na; ++a) {
-      int i = act[a];
+      const int i = act[a];
       for (int j = 0; j < n; ++j) {
-        double gij = i < n ? (i == j ? 1.0 : 0.0) : A[IDX(i - n, j, m)];
+        const double gij = i < n ? (i == j ? 1.0 : 0.0) : A[IDX(i - n, j, m)];
         KK[IDX(n + a, j, K)] = gij;
-        KK[IDX(j, n + a, K)] = -gij; /* H x - G_a' lam = -g */
+        KK[IDX(j, n + a, K)] = -gij;
       }
-      r[n + a] = rhs_a[a];
+      const double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
+      r[n + a] = side[i] > 0 ? l : u;
     }
     for (int j = 0; j < n; ++j) r[j] = -g[j];
-    if (lu_solve(K, KK, r) == 0) {
-      /* accept only if still primal feasible and duals keep their sign (to tight tolerance) */
-      double* v2 = (double*)calloc(mt, sizeof(double));
-      for (int i = 0; i < n; ++i) v2[i] = r[i];
-      for (int j = 0; j < n; ++j) for (int rr = 0; rr < m; ++rr) v2[n + rr] += A[IDX(rr, j, m)] * r[j];
-      int good = 1;
-      double dxmax = 0, xmax = 1;
-      for (int i = 0; i < n; ++i) { dxmax = fmax(dxmax, fabs(r[i] - x[i])); xmax = fmax(xmax, fabs(x[i])); }
-      (void)dxmax; (void)xmax; /* acceptance is by KKT alone: feasibility + multiplier signs certify optimality */
-      for (int i = 0; i < mt && good; ++i) {
-        double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
-        double sc = fmax(1.0, fabs(v2[i]));
-        if (l > -INFINITY && v2[i] < l - 1e-9 * fmax(sc, fabs(l))) good = 0;
-        if (u < INFINITY && v2[i] > u + 1e-9 * fmax(sc, fabs(u))) good = 0;
+    const int sing = lu_solve(K, KK, r);
+    if (!sing) {
+      for (int i = 0; i < n; ++i) { xs[i] = r[i]; v[i] = r[i]; }
+      for (int rr = 0; rr < m; ++rr) v[n + rr] = 0;
+      for (int j = 0; j < n; ++j) for (int rr = 0; rr < m; ++rr) v[n + rr] += A[IDX(rr, j, m)] * r[j];
+      double ymax = 1.0;
+      for (int a = 0; a < na; ++a) ymax = fmax(ymax, fabs(r[n + a]));
+      double worst_v = 0, worst_s = 0; int iv = -1, sv = 0, is = -1;
+      for (int i = 0; i < mt; ++i) {
+        if (side[i]) continue;
+        const double l = i < n ? lb[i] : lbA[i - n], u = i < n ? ub[i] : ubA[i - n];
+        double sc = fmax(1.0, fabs(v[i]));
+        if (l > -inf_bound) { const double vl = (l - v[i]) / fmax(sc, fabs(l)); if (vl > worst_v) { worst_v = vl; iv = i; sv = 1; } }
+        if (u < inf_bound) { const double vu = (v[i] - u) / fmax(sc, fabs(u)); if (vu > worst_v) { worst_v = vu; iv = i; sv = -1; } }
       }
-      for (int a = 0; a < na && good; ++a) {
-        double lam_new = r[n + a], lam_old = lambda[act[a]];
-        if (lam_new * lam_old < 0 && fabs(lam_new) > 1e-9 * fmax(1.0, fabs(lam_old))) good = 0;
+      for (int a = 0; a < na; ++a) {
+        const double y = r[n + a], sg = (side[act[a]] > 0 ? -y : y) / ymax;
+        if (sg > worst_s) { worst_s = sg; is = act[a]; }
       }
-      if (good) {
-        for (int i = 0; i < n; ++i) x[i] = r[i];
+      if (worst_v <= ftol && worst_s <= stol) {
+        for (int i = 0; i < n; ++i) x[i] = xs[i];
         for (int i = 0; i < mt; ++i) lambda[i] = 0;
-        for (int a = 0; a < na; ++a) lambda[act[a]] = r[n + a];
+        for (int a = 0; a < na; ++a) {
+          const double y = r[n + a];
+          lambda[act[a]] = side[act[a]] > 0 ? fmax(y, 0.0) : fmin(y, 0.0);
+        }
         ok = 1;
-      }
-      free(v2);
+      } else if (worst_v > ftol && iv >= 0) side[iv] = sv;
+      else if (is >= 0) side[is] = 0;
     }
     free(KK); free(r);
+    if (sing) break;
   }
-  free(act); free(rhs_a); free(v);
+  free(side); free(act); free(v); free(xs);
   return ok;
 }
 
 int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double* A,
                  const double* lb, const double* ub, const double* lbA, const double* ubA,
                  const orc_qp_opts* opts_in, double* x_out, double* fval_out, int* iter_out, double* lambda_out) {
+  return orc_qp_solve_ex(nV, nC, H, g, A, lb, ub, lbA, ubA, opts_in, x_out, fval_out, iter_out, lambda_out, 0, 0);
+}
+
+/* Exit semantics (qpOASES.m:43-47 codes): x_out always carries the last (or best saved) iterate -- the reference keeps
+ * driving on whatever the solver returned (main.m:163-175) -- NaN only if the data already held one.  -3 (unbounded) is
+ * returned only when the objective follows a diverging x to -infinity; a diverging iterate on a bounded problem is an
+ * internal failure (-1).  kkt_out: relative KKT residual (max of stationarity, primal, complementarity) of the returned
+ * point as the solver measured it; polished_out: 1 if the active-set refinement was accepted. */
+int orc_qp_solve_ex(int nV, int nC, const double* H, const double* g, const double* A,
+                    const double* lb, const double* ub, const double* lbA, const double* ubA,
+                    const orc_qp_opts* opts_in, double* x_out, double* fval_out, int* iter_out, double* lambda_out,
+                    double* kkt_out, int* polished_out) {
   orc_qp_opts opts;
   if (opts_in) opts = *opts_in; else orc_qp_default_opts(&opts);
   const int n = nV, m = nC, mt = n + m;
-  int flag = 1, it = 0;
+  int flag = 1, it = 0, pol_done = 0;
+  double last_merit = INFINITY, fval_it = 0;
   qp_work w;
   w.n = n; w.m = m; w.mt = mt;
   w.H = (double*)malloc(sizeof(double) * n * n);
@@ -388,6 +443,7 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
      * the best qualified iterate is returned when the next steps turn to numerical garbage */
     const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
     const int res_ok = merit <= opts.tol;
+    last_merit = merit; fval_it = fval;
     if (merit <= opts.tol_loose && merit < saved_merit) {
       for (int j = 0; j < n; ++j) xs[j] = x[j];
       for (int i = 0; i < mt; ++i) lams[i] = (w.hl[i] ? zl[i] : 0) - (w.hu[i] ? zu[i] : 0);
@@ -538,7 +594,7 @@ int orc_qp_solve(int nV, int nC, const double* H, const double* g, const double*
     double xn = 0, zn = 0;
     for (int j = 0; j < n; ++j) xn = fmax(xn, fabs(x[j]));
     for (int i = 0; i < mt; ++i) zn = fmax(zn, fmax(w.hl[i] ? zl[i] : 0, w.hu[i] ? zu[i] : 0));
-    if (xn > 1e13) { flag = -3; break; }
+    if (xn > 1e13) { flag = rp_rel > 1e-6 ? -2 : (fval_it < -1e13 ? -3 : -1); break; }
     if (zn > 1e15 && rp_rel > 1e-6) { flag = -2; break; }
     /* once an iterate met tol_loose, a handful of non-improving iterations means the end game has lost its
      * numerical footing: stop early and return the saved iterate (bounds the iteration tail of a batch) */
@@ -550,10 +606,10 @@ finish:
     /* fall back to the last iterate that met the residual tolerances */
     for (int j = 0; j < n; ++j) x[j] = xs[j];
     for (int i = 0; i < mt; ++i) { zl[i] = lams[i] > 0 ? lams[i] : 0; zu[i] = lams[i] < 0 ? -lams[i] : 0; }
-    flag = 0;
+    flag = 0; last_merit = saved_merit;
   }
-  /* unscale */
-  if (flag == 0 || flag == 1 || flag == 4) {
+  /* unscale: the last iterate is returned whatever the exit code */
+  {
     for (int j = 0; j < n; ++j) x_out[j] = x[j] * w.E[j];
     if (lambda_out) {
       for (int j = 0; j < n; ++j) lambda_out[j] = ((w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0)) / w.E[j];
@@ -568,13 +624,13 @@ finish:
       }
       const int pol_ok = polish(n, m, H, g, A, lb, ub, lbA, ubA, opts.inf_bound, x_out, lam);
       if (flag == 4) flag = pol_ok ? 0 : -1;
+      pol_done = pol_ok;
+      if (pol_ok) last_merit = orc_qp_kkt(n, m, H, g, A, lb, ub, lbA, ubA, x_out, lam, opts.inf_bound, 0);
       if (!lambda_out) free(lam);
     }
   }
-  if (!(flag == 0 || flag == 1)) {
-    for (int j = 0; j < n; ++j) x_out[j] = NAN;
-    if (lambda_out) for (int i = 0; i < mt; ++i) lambda_out[i] = NAN;
-  }
+  if (kkt_out) *kkt_out = last_merit;
+  if (polished_out) *polished_out = pol_done;
   if (fval_out) {
     double f = 0;
     for (int j = 0; j < n; ++j) {
@@ -622,10 +678,10 @@ int orc_ltv_step(int model, int N, double dt, const orc_spline* sp,
   return flag;
 }
 
-int orc_qp_solve_batch(int nV, int nC, int batch, const double* H, const double* g, const double* A,
-                       const double* lb, const double* ub, const double* lbA, const double* ubA,
-                       const orc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
-                       double* lambda, int threads) {
+int orc_qp_solve_batch_ex(int nV, int nC, int batch, const double* H, const double* g, const double* A,
+                          const double* lb, const double* ub, const double* lbA, const double* ubA,
+                          const orc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
+                          double* lambda, double* kkt, int* polished, int threads) {
   int used = 1;
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
@@ -633,13 +689,22 @@ int orc_qp_solve_batch(int nV, int nC, int batch, const double* H, const double*
 #endif
 #pragma omp parallel for schedule(dynamic, 1)
   for (int b = 0; b < batch; ++b) {
-    int it = 0; double fv = 0;
-    int fl = orc_qp_solve(nV, nC, H + (size_t)b * nV * nV, g + (size_t)b * nV, A + (size_t)b * nC * nV,
-                          lb + (size_t)b * nV, ub + (size_t)b * nV, lbA + (size_t)b * nC, ubA + (size_t)b * nC, opts,
-                          x + (size_t)b * nV, &fv, &it, lambda ? lambda + (size_t)b * (nV + nC) : 0);
+    int it = 0, pol = 0; double fv = 0, kk = 0;
+    int fl = orc_qp_solve_ex(nV, nC, H + (size_t)b * nV * nV, g + (size_t)b * nV, A + (size_t)b * nC * nV,
+                             lb + (size_t)b * nV, ub + (size_t)b * nV, lbA + (size_t)b * nC, ubA + (size_t)b * nC, opts,
+                             x + (size_t)b * nV, &fv, &it, lambda ? lambda + (size_t)b * (nV + nC) : 0, &kk, &pol);
     if (fval) fval[b] = fv;
     if (exitflag) exitflag[b] = fl;
     if (iter) iter[b] = it;
+    if (kkt) kkt[b] = kk;
+    if (polished) polished[b] = pol;
   }
   return used;
+}
+
+int orc_qp_solve_batch(int nV, int nC, int batch, const double* H, const double* g, const double* A,
+                       const double* lb, const double* ub, const double* lbA, const double* ubA,
+                       const orc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter,
+                       double* lambda, int threads) {
+  return orc_qp_solve_batch_ex(nV, nC, batch, H, g, A, lb, ub, lbA, ubA, opts, x, fval, exitflag, iter, lambda, 0, 0, threads);
 }

@@ -47,9 +47,11 @@ def run_car(args):
         flags.append(fl); iters.append(it)
         if fl != 0:
             fails.append(dict(car=car, step=t, flag=fl, **{k_: q[k_].copy() for k_ in ("H", "g", "A", "lb", "ub", "lbA", "ubA")}))
-            continue   # the car keeps its state for this step (ClosedLoop.step)
-        pred = q["A_bar"] @ x0 + q["Bt"] @ z + q["d_bar"]
-        x_opt = np.asfortranarray(pred.reshape(N, nx).T); u_opt = np.asfortranarray(z[:2 * N].reshape(N, 2).T)
+        if fl in (0, 1) and np.isfinite(z).all():   # plan taken over (fsaempc_cl_accept_batch_device); else the car drives on its last good plan
+            pred = q["A_bar"] @ x0 + q["Bt"] @ z + q["d_bar"]
+            x_opt = np.asfortranarray(pred.reshape(N, nx).T); u_opt = np.asfortranarray(z[:2 * N].reshape(N, 2).T)
+        if not np.isfinite(cart).all() or np.abs(cart).max() > 1e6:
+            break
         cart, pid, _ = orc.plant_step(cart, pid, x_opt[3, 0], x_opt[nx - 1, 0], dt)
     return car, flags, iters, fails
 

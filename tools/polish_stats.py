@@ -13,14 +13,9 @@ def run(model, N, B):
     q = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul)
     xo, fo, flo, ito, lamo, _ = orc.qp_solve_batch(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"])
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    pol = torch.zeros(B, dtype=torch.int32, device="cuda")
-    fm.lib().fsaempc_debug_set_polished(C.c_void_p(pol.data_ptr()))
-    dmp = torch.zeros(1 << 16, dtype=torch.float64, device="cuda")
-    fm.lib().fsaempc_debug_set_dump(C.c_void_p(dmp.data_ptr()), 3)
-    out = fm.qp_solve_batch_device(dev(q["H"]), dev(q["g"]), dev(q["A"]), dev(q["lb"]), dev(q["ub"]), dev(q["lbA"]), dev(q["ubA"]), want_lambda=True)
+    out = fm.qp_solve_batch_device(dev(q["H"]), dev(q["g"]), dev(q["A"]), dev(q["lb"]), dev(q["ub"]), dev(q["lbA"]), dev(q["ubA"]), want_lambda=True, want_aux=True)
     torch.cuda.synchronize()
-    fm.lib().fsaempc_debug_set_polished(None)
-    fm.lib().fsaempc_debug_set_dump(None, 0)
+    pol = out["polished"]
     # refinement codes: 1 accepted; -1 stationarity, -2 primal feasibility, -3 complementarity, -4 multiplier sign,
     # -5 factorisation, -6 CG did not converge in 7 steps, -7 CG breakdown (dependent / inconsistent working set)
     code = pol.cpu().numpy(); pol = code > 0
