@@ -4,8 +4,12 @@
 Workload (BASELINE.json configs[1]): batch of 4096 independent condensed QPs per GPU, curvilinear kinematic
 bicycle, N=40 (nV=81, nC=240), fp64, generic mode of SURVEY 8(d): the dense (H,g,A,lb,ub,lbA,ubA) tensors are
 resident in HBM when the timed region starts; one step = one batched solve (+ the RCCL gather of x when N>1).
-  python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
-Rank 0 prints ONE JSON line.  cpu_baseline = the CPU oracle timed on the host cores (a reported baseline)."""
+  python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU over RCCL.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) this
+process is one rank; started plainly it spawns the N ranks itself (a child `python -m torch.distributed.run ... bench.py`
+-- before anything here touches the GPU) and relays rank 0's line.  Rank 0 prints ONE JSON line.
+cpu_baseline = the CPU oracle timed on the host cores (a reported baseline).  --dry-run exercises the launch, sharding,
+gather and reporting path without a GPU (gloo, zeros instead of solves; used by tests/test_abi_cpu.py)."""
 import argparse
 import ctypes as C
 import json
@@ -30,7 +34,21 @@ def main():
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--model", default="kinematic", choices=["kinematic", "dynamic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: launch / shard / gather / report path only (CPU, gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-start: one child launcher, N ranks; this parent never initialises the GPU
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -45,8 +63,10 @@ def main():
     rehearsal = os.environ.get("FSAEMPC_BENCH_REHEARSAL") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        dist.init_process_group("gloo" if (rehearsal or args.dry_run) else "nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    if args.dry_run:
+        return dry_run(args, rank, world)
     dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
 
@@ -67,7 +87,7 @@ def main():
 
     def step():
         nonlocal ws
-        out = fm.qp_solve_batch_device(*qp_args, workspace=ws)
+        out = fm.qp_solve_batch_device(*qp_args, workspace=ws, want_aux=True)
         ws = out["workspace"]
         if world > 1:
             xs = out["x"].cpu() if rehearsal else out["x"]
@@ -99,7 +119,10 @@ def main():
 
     flags = out["exitflag"].cpu().numpy()
     iters = out["iter"].cpu().numpy()
-    solved = int((flags == 0).sum())
+    kkt_dev = out["kkt"].cpu().numpy()
+    polished = out["polished"].cpu().numpy()
+    TOL_KKT = 1e-6                                            # the specified tolerance (BASELINE.json north_star)
+    solved = int(((flags == 0) & (kkt_dev <= TOL_KKT)).sum())   # an instance counts only if it is solved to that tolerance
     n_ok = shard.max_over_ranks(float(-solved), device=rdev)  # min over ranks via max of negatives
     solved_total = shard.sum_over_ranks(float(solved), device=rdev)
     # fused mode of SURVEY 8(d) (x0, x_ref, x_lin, u_lin -> u_opt, x_opt: construction + solve + post-solve), timed
@@ -152,34 +175,39 @@ def main():
         "config": {"workload": "%s: batch=%d independent condensed QPs per GPU, %s model, N=%d, nV=%d, nC=%d, generic mode (dense H,g,A,bounds resident in HBM)"
                                % ("BASELINE configs[1]" if (args.model == "kinematic" and N == 40 and Bl == 4096) else "non-headline shape", Bl, args.model, N, nV, nC),
                    "batch_per_gpu": Bl, "global_batch": Btot, "track": "fsg2019", "seed": 20190,
-                   "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "solved_total": int(solved_total), "tol_kkt": 1e-8,
+                   "mean_ipm_iterations": mean_it, "solved_min_per_rank": int(-n_ok), "solved_total": int(solved_total),
+                   "tol_kkt": TOL_KKT, "kkt_reported_by_kernel_max_rank0": float(kkt_dev[flags == 0].max()) if (flags == 0).any() else None,
+                   "on_vertex_fraction_rank0": float((polished > 0).mean()),
                    "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,
                    "fused_mode_qp_per_s_rank0": fused_rate,
                    "iteration_histogram_rank0": it_hist, "exitflag_histogram_rank0": fl_hist,
                    "max_rel_kkt_rank0": {"stationarity": kkt_max[0], "primal": kkt_max[1], "complementarity": kkt_max[2]},
                    "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
-        "roofline": {"bound": "mfma", "kernel": "qp_solve_kernel<%d, %d>" % ((nV // 16, 1 if nV % 16 == 1 else 4) if (nV >= 16 and 1 <= nV % 16 <= 4) else ((nV + 15) // 16, 0)), "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": ("qp_solve_kernel<%d, %d>" % (nV // 16, 1 if nV % 16 == 1 else 4)) if (16 <= nV <= 84 and 1 <= nV % 16 <= 4) else "qp_wg_kernel<%d, ...>" % ((nV + 15) // 16 if not (1 <= nV % 16 <= 4) else nV // 16), "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                      "flops_per_launch": flops_launch, "algorithmic_bytes_per_solve": bytes_solve,
                      "hbm_frac_one_pass": bytes_solve * Bl / (k_ms * 1e-3) / 8e12},
     }
 
-    # HBM-side traffic of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py; rocprofv3 --pmc FETCH_SIZE
-    # and --pmc WRITE_SIZE in separate runs, gfx950 corrections applied) -- only for the workload they were measured on
-    pmc = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_kinN40_B4096.json")
-    if os.path.exists(pmc) and args.model == "kinematic" and N == 40 and Bl == 4096:
-        with open(pmc) as f:
-            res["roofline"]["traffic"] = json.load(f)["traffic_bytes_per_launch"]
-        res["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side, PMC, see profiles/round1/pmc_traffic_kinN40_B4096.json)"
+    # Counter-based figures of the dominant kernel are ARCHIVED measurements (rocprofv3 --pmc needs its own passes and cannot run
+    # inside this process): HBM-side traffic (tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections) and
+    # matrix-core busy share (SQ_VALU_MFMA_BUSY_CYCLES pass), committed under profiles/round2/ for exactly this workload
+    for key, fname, field in (("traffic", "pmc_traffic_kinN40_B4096.json", "traffic_bytes_per_launch"), ("mfma_busy", "pmc_mfma_kinN40_B4096.json", "mfma_busy_frac")):
+        path = os.path.join(ROOT, "profiles", "round2", fname)
+        if os.path.exists(path) and args.model == "kinematic" and N == 40 and Bl == 4096:
+            with open(path) as f:
+                res["roofline"][key] = json.load(f)[field]
+            res["roofline"][key + "_source"] = "archived PMC pass of this workload: profiles/round2/" + fname
+    if res["roofline"]["traffic"] is not None:
+        res["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side; Infinity-Cache hits are counted, so an upper bound on HBM bytes)"
 
     res["cpu_baseline"] = None    # timed on rank 0 at N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle as orc
         otr = orc.Track.load(os.path.join(ROOT, "fsae-mpc_amd", "tracks", "fsg2019.json"))
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        cores = min(cores, 16)   # the GPU box's CPU share for one GPU
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)   # every host core this process may use
         H, g, A, lb, ub, lbA, ubA = (t.cpu().numpy() for t in qp_args)
-        o = orc.default_opts(polish=0)
+        o = orc.default_opts()                                  # same options as the GPU leg (refinement on)
         pilot = min(Bl, 4 * cores)
         t1 = time.perf_counter()
         orc.qp_solve_batch(H[:pilot], g[:pilot], A[:pilot], lb[:pilot], ub[:pilot], lbA[:pilot], ubA[:pilot], o, threads=cores, want_lambda=False)
@@ -190,11 +218,35 @@ def main():
                                                         threads=cores, want_lambda=False)
         tc = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": sample / tc, "unit": "QP solves/s", "cores": int(used), "kind": "port",
-                               "sample": "first %d instances of the same batch, same (H,g,A,bounds), oracle IPM (no polish), OpenMP over instances; "
-                                         "reference-equivalent CPU path (MATLAB+qpOASES cannot run here)" % sample,
+                               "sample": "first %d instances of the same batch, same (H,g,A,bounds) and the same options (interior-point method + "
+                                         "active-set refinement), plain-C oracle with OpenMP over instances on all %d cores this process may use; "
+                                         "reference-equivalent CPU path (MATLAB+qpOASES cannot run here)" % (sample, cores),
                                "mean_ipm_iterations": float(it_c.mean()), "solved": int((fl_c == 0).sum())}
     if rank == 0:
         print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def dry_run(args, rank, world):
+    """Launch / shard / gather / report path without a GPU (tests/test_abi_cpu.py): every rank contributes a zero block of x for its
+    index-pure shard; the gather, the max-over-ranks timing and rank 0's JSON line are the real code."""
+    import torch
+    import torch.distributed as dist
+    from fsae_mpc_amd import shard
+    Bl = args.batch
+    lo, hi = shard.shard_range(Bl * world, rank, world)
+    x_local = torch.full((hi - lo, 3), float(rank), dtype=torch.float64)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x_all = shard.gather_rows(x_local, Bl * world, rank, world) if world > 1 else x_local
+    t_job = shard.max_over_ranks(time.perf_counter() - t0, device="cpu")
+    ok = bool((x_all[lo:hi] == float(rank)).all()) and x_all.shape[0] == Bl * world
+    if rank == 0:
+        print(json.dumps({"metric": "QP solves/sec (dry run: no solves)", "value": 0.0, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * t_job / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": "dry run", "gathered_rows": int(x_all.shape[0]), "gather_ok": ok},
+                          "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

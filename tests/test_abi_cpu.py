@@ -102,3 +102,22 @@ def test_sharding_and_gather_over_gloo():
     for p in ps: p.join(60)
     assert res[0][1:3] == (0, 19) and res[1][1:3] == (19, 37)
     assert all(r[3] for r in res) and all(r[4] == 2.0 for r in res)
+
+
+def test_bench_self_starts_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher around it starts its own ranks: the dry run takes the same
+    launch -> init_process_group -> shard -> gather_rows -> max_over_ranks -> one JSON line route as the GPU run, on gloo."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--batch", "37", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["gathered_rows"] == 74 and out["config"]["gather_ok"]
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline"):
+        assert k in out
