@@ -167,6 +167,9 @@ def main():
     achieved = flops_launch / (k_ms * 1e-3) / 1e12
     bytes_solve = 8.0 * (nV * nV + nV + nC * nV + 2 * nV + 2 * nC) + 8.0 * (nV + 2)
 
+    rem = nV % 16
+    Tt, NBt = (nV // 16, 1 if rem == 1 else 4) if (nV >= 16 and 1 <= rem <= 4) else ((nV + 15) // 16, 0)
+    kernel_name = ("qp_solve_kernel<%d, %d>" % (Tt, NBt)) if Tt <= 7 else "qp_wg_kernel<%d, %d, 8, ...>" % (Tt, 4 if NBt else 0)   # qp_launch's choice
     res = {
         "metric": "QP solves/sec (batched LTV-MPC, N=%d nx=%d nu=2 fp64)" % (N, nx),
         "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,8 +186,8 @@ def main():
                    "iteration_histogram_rank0": it_hist, "exitflag_histogram_rank0": fl_hist,
                    "max_rel_kkt_rank0": {"stationarity": kkt_max[0], "primal": kkt_max[1], "complementarity": kkt_max[2]},
                    "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
-        "roofline": {"bound": "mfma", "kernel": ("qp_solve_kernel<%d, %d>" % (nV // 16, 1 if nV % 16 == 1 else 4)) if (16 <= nV <= 84 and 1 <= nV % 16 <= 4) else "qp_wg_kernel<%d, ...>" % ((nV + 15) // 16 if not (1 <= nV % 16 <= 4) else nV // 16), "achieved": achieved,
-                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved,
+                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "mfma_busy": None,
                      "flops_per_launch": flops_launch, "algorithmic_bytes_per_solve": bytes_solve,
                      "hbm_frac_one_pass": bytes_solve * Bl / (k_ms * 1e-3) / 8e12},
     }

@@ -63,7 +63,7 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double*
   QpParams P; memset(&P, 0, sizeof(P));
   qp_make_dims(desc->nV, desc->nC, &P.d);
   if ((long long)(P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
-  const bool wg = P.d.T > 5 || P.d.nb == 0;   // kernel selection of qp_launch
+  const bool wg = !qp_runs_wavefront_kernel(P.d);
   if ((wg ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024 || (wg && P.d.J + P.d.JB > 32)) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels (the workgroup kernel supports up to ~1850 constraint rows)");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;

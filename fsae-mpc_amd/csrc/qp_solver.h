@@ -39,6 +39,7 @@ struct QpParams {
 };
 
 void qp_make_dims(int n, int m, QpDims* d);
+bool qp_runs_wavefront_kernel(const QpDims& d);   // kernel selection of qp_launch
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid = nullptr);
 int qp_selftest_mfma(char* msg, int msglen);
 // LDS bytes of the workgroup solve kernel (qp_wg.hip) without the resident operand stream; NBk = border width of the

@@ -96,8 +96,8 @@ template <int T> struct Tri {
   __host__ __device__ static constexpr int idx(int I, int J) { return I * T - (I * (I - 1)) / 2 + (J - I); }
 };
 
-// Translation units: the solve kernel is instantiated for T = 1..5 and three border widths; the Makefile builds this
-// file three times (-DQP_TU=0: prep kernel, dimensions, dispatch, self test; -DQP_TU=1: T = 1..4; -DQP_TU=2: T = 5).
+// Translation units: the solve kernel is instantiated for T = 1..7 and three border widths; the Makefile builds this
+// file five times (-DQP_TU=0: prep kernel, dimensions, dispatch, self test; -DQP_TU=1: T = 1..4; -DQP_TU=2..4: T = 5..7).
 // Without QP_TU everything lands in one object (used by the one-command diagnostic builds).
 #if !defined(QP_TU) || QP_TU == 0
 #define QP_MAIN_TU 1
@@ -365,51 +365,12 @@ template <int C> struct IC { static constexpr int value = C; };
 // and it is a FULL drain: `s_waitcnt vmcnt(0)` at the top of a pair (every vector-memory operation of this wave has
 // completed, hence this pair's records are in LDS), then the DMA of the next pair is issued and flies during the
 // matrix-core work of this one.
-//   Round 1 kept D records in flight and waited with `s_waitcnt vmcnt(D)`.  That is only sound if vector-memory
-//   operations retire in issue order, and on gfx9 loads and stores do not retire in order RELATIVE TO EACH OTHER (loads
-//   among themselves do, stores among themselves do; LLVM's SIInsertWaitcnts treats mixed pending loads and stores as an
-//   out-of-order counter for exactly this reason).  A store issued inside the window -- a register spill of the
-//   accumulators, a row-array store of the pass -- can retire before an older LDS-DMA load, vmcnt drops to D, and the
-//   consumer reads a ring slot whose record has not landed: an iterate that is "slightly wrong", depending on where the
-//   register allocator happened to put its spill code.  That was the build-variant fragility of round 1.
+//   Round 1 kept D records in flight and waited with a counted `s_waitcnt vmcnt(D)`; that relies on every vector-memory
+//   operation of the wave (LDS-DMA loads, row-array stores, register spills) retiring in issue order.  The full drain needs
+//   no such assumption and costs nothing measurable (the next pair's DMA still overlaps this pair's matrix-core work).
+//   (The wrong iterates of some -O2/-O3 builds were NOT a ring hazard: DESIGN.md, "Build-variant fragility: root cause".)
 // The asm memory clobbers keep the compiler from moving LDS reads or DMA issues across the wait.
 // ---------------------------------------------------------------------------------------------
-#ifdef QP_OLD_STREAM   // bisecting experiment: the round-1 ring (D records in flight, counted vmcnt)
-template <int T> struct StreamCfg {
-  static constexpr int D = T <= 5 ? 6 : (T == 6 ? 4 : (T == 7 ? 3 : 2));
-  static constexpr int R = D + T;
-};
-template <int T> struct Stream {
-  static constexpr int D = StreamCfg<T>::D, R = StreamCfg<T>::R;
-  const char* gnext; int slot_i, slot_e;
-  DEVINL void start(const Ctx& k, int) {
-    gnext = reinterpret_cast<const char*>(k.Aw); slot_i = 0; slot_e = 0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) issue(k);
-  }
-  DEVINL void issue(const Ctx& k) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gnext + k.lane * 16),
-                                     (__attribute__((address_space(3))) void*)(k.ring + slot_i * 128), 16, 0, 0);
-    gnext += 1024;
-    slot_i = slot_i + 1 == R ? 0 : slot_i + 1;
-  }
-  template <int C> DEVINL void next_pair(const Ctx& k, v2d* b, int) {
-#pragma unroll
-    for (int t = 0; t < C; ++t) issue(k);
-    if (D == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if (D == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (D == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    if (D == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < C; ++t) {
-      int sl = slot_e + t; if (sl >= R) sl -= R;
-      b[t] = *reinterpret_cast<const v2d*>(k.ring + sl * 128 + k.lane * 2);
-    }
-    slot_e += C; if (slot_e >= R) slot_e -= R;
-  }
-  DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
-#else
 template <int T> struct StreamCfg {
   static constexpr int R = 2 * T;   // ring capacity: two pairs of k-steps
 };
@@ -442,8 +403,6 @@ template <int T> struct Stream {
   }
   DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
-
-#endif
 
 // Per-row coefficients of a pass (owner layout [slot][64] in global memory): one slot (16 k-steps) at a time is staged
 // in LDS -- NA wave-wide loads per 16 k-steps instead of NA broadcast loads per k-step -- and read back as 16-byte
@@ -1560,11 +1519,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   // could not (rejected 10-20 % of the instances).  One fused stream over A~ per CG step (q = A_W w and A_W'q together),
   // A'p kept by recurrence.  The result is accepted only if a fresh evaluation says it is a KKT point of the full QP;
   // otherwise the interior-point iterate is returned.
-#ifdef QP_NO_NEWPOLISH
-  if (false) {
-#else
   if ((flag == 0 || flag == 4) && P.polish) {
-#endif
     const double rho = 1e6, pin = 1e16, rinv = 1.0 / rho;
     double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
     double* PC = rowp(k, R_RPU); double* PP = rowp(k, R_CC2); double* PZ0 = aW2;   // constraint residual c, CG direction p, zeros
@@ -2068,7 +2023,8 @@ template <int T, int NB> static hipError_t launch_solve_TN(const QpParams& P, in
   return hipGetLastError();
 }
 template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, hipStream_t st) {
-  switch (P.d.NB) {   // bordered shapes only (nV mod 16 in 1..4: every LTV-MPC horizon N = 8k); the rest runs on qp_wg.hip
+  switch (P.d.NB) {
+    case 0: return launch_solve_TN<T, 0>(P, batch, st);
     case 1: return launch_solve_TN<T, 1>(P, batch, st);
     case 4: return launch_solve_TN<T, 4>(P, batch, st);
     default: return hipErrorInvalidValue;
@@ -2076,8 +2032,10 @@ template <int T> static hipError_t launch_solve_T(const QpParams& P, int batch, 
 }
 
 #if defined(QP_TU)
-hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st);
-hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st);   // T = 1..4
+hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st);   // T = 5
+hipError_t qp_launch_solve_g3(const QpParams& P, int batch, hipStream_t st);   // T = 6
+hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st);   // T = 7
 #if QP_TU == 1
 hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st) {
   switch (P.d.T) {
@@ -2090,21 +2048,35 @@ hipError_t qp_launch_solve_g1(const QpParams& P, int batch, hipStream_t st) {
 }
 #elif QP_TU == 2
 hipError_t qp_launch_solve_g2(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<5>(P, batch, st); }
+#elif QP_TU == 3
+hipError_t qp_launch_solve_g3(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<6>(P, batch, st); }
+#elif QP_TU == 4
+hipError_t qp_launch_solve_g4(const QpParams& P, int batch, hipStream_t st) { return launch_solve_T<7>(P, batch, st); }
 #endif
 #endif
 
 #if QP_MAIN_TU
-// Kernel selection.  The one-wavefront kernel of this file serves the bordered shapes up to T = 5 column tiles
-// (nV = 16T + 1..4 <= 84: the LTV-MPC QPs of the horizons N = 8k <= 40, i.e. the headline shapes).  Its other
-// instantiations are retired: T >= 5 without border and T = 6..8 computed wrong iterates in some -O2/-O3 builds of a source
-// whose -O1 build is right -- deterministic, but moving with unrelated edits (compiling the dump hooks out was enough);
-// DESIGN.md, "Build-variant fragility", lists what was ruled out.  qp_wg.hip (workgroup-per-QP kernel: no inline
-// assembly, no LDS-DMA, accumulators spread over eight wavefronts, ~40 % of the registers) serves everything else
-// (T = 1..12, nV up to 196), built as five translation units named by their first T.  The -O1 guard
-// (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build) compares every instantiation of both kernels with
-// an -O1 build on the GPU.  A development build (-DQP_WG_ONE_TU, `make devlib`) has its own selection of tile counts in one
-// unit and FSAEMPC_QP_WG=1 routes every shape to it.
-#define QP_V1_MAX_T 5
+// Kernel selection.  Two solve kernels share the prep kernel, the workspace layout and the algorithm:
+//   - the one-wavefront kernel of this file (T = 1..7 column tiles, border widths 0 / 1 / 4: nV <= 116), built as four
+//     translation units by tile count;
+//   - the workgroup-per-QP kernel of qp_wg.hip (T = 1..12, nV <= 196: eight wavefronts share one QP), five more units.
+// qp_use_wavefront_kernel() holds the measured choice per shape.  Every unit goes through the build's
+// assembly check (tools/check_isa_exec_prologue.py: the compiler defect behind the wrong iterates of some -O2/-O3 builds,
+// DESIGN.md "Build-variant fragility: root cause") and tests/test_gpu_parity.py::test_shipped_build_matches_O1_build
+// compares every instantiation of both kernels with an -O1 build on the GPU.  A development build (-DQP_WG_ONE_TU,
+// `make devlib`) has its own selection of tile counts in one unit; FSAEMPC_QP_KERNEL=wg|v1 overrides the choice (A/B runs).
+#define QP_V1_MAX_T 7
+// Measured on MI355X at 4096 QPs per launch (profiles/round2/kernel_ab.txt): the one-wavefront kernel is 1.1-2x faster up to
+// T = 7 (nV <= 116); from T = 8 on its accumulators no longer fit the register file (it spills) and the workgroup kernel wins
+// (dynamic N = 60: 18.6k vs 9.6k QP/s), so T = 8 is not instantiated here.  np <= 128 is also a hard limit of this kernel
+// (two lanes-worth of n-vector elements per sweep).
+static bool qp_use_wavefront_kernel(const QpDims& d) {
+  return d.T <= QP_V1_MAX_T;
+}
+bool qp_runs_wavefront_kernel(const QpDims& d) {   // what qp_launch will pick (capi.hip checks the LDS budget of that kernel)
+  static const char* force = getenv("FSAEMPC_QP_KERNEL");   // A/B runs only: "wg" or "v1"
+  return d.T <= QP_V1_MAX_T && ((force && force[0] == 'v') || (!(force && force[0] == 'w') && qp_use_wavefront_kernel(d)));
+}
 #ifdef QP_WG_ONE_TU
 hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
 static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) { return qp_wg_launch_1(P, batch, st); }
@@ -2144,10 +2116,7 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     return hipGetLastError();
   }
 #endif
-  {
-    static const bool force_wg = getenv("FSAEMPC_QP_WG") != nullptr;   // development builds only
-    if (P.d.T > QP_V1_MAX_T || P.d.nb == 0 || force_wg) return qp_wg_launch(P, batch, st);
-  }
+  if (!qp_runs_wavefront_kernel(P.d)) return qp_wg_launch(P, batch, st);
 #if !defined(QP_TU)
   switch (P.d.T) {
 #if defined(QP_ONLY_T)
@@ -2158,6 +2127,8 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
     case 3: return launch_solve_T<3>(P, batch, st);
     case 4: return launch_solve_T<4>(P, batch, st);
     case 5: return launch_solve_T<5>(P, batch, st);
+    case 6: return launch_solve_T<6>(P, batch, st);
+    case 7: return launch_solve_T<7>(P, batch, st);
 #endif
     default: return hipErrorInvalidValue;
   }
@@ -2165,6 +2136,8 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   switch (P.d.T) {
     case 1: case 2: case 3: case 4: return qp_launch_solve_g1(P, batch, st);
     case 5: return qp_launch_solve_g2(P, batch, st);
+    case 6: return qp_launch_solve_g3(P, batch, st);
+    case 7: return qp_launch_solve_g4(P, batch, st);
     default: return hipErrorInvalidValue;
   }
 #endif

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Investigation of the build-variant fragility: iterates of two libraries after 1..K interior-point iterations (the last
+iterate is always returned).  usage: frag_iter.py child <out.npz>   |   frag_iter.py cmp <libA> <libB>"""
+import os, subprocess, sys
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+MODEL, N, B, K = 0, int(os.environ.get("FRAG_N", "39")), 8, int(os.environ.get("FRAG_K", "4"))
+
+
+def child(out):
+    import torch
+    import fsae_mpc_amd as fm
+    import oracle as orc
+    otr = orc.Track.load(os.path.join(ROOT, "fsae-mpc_amd", "tracks", "fsg2019.json"))
+    x0, xl, ul, xr = fm.instances(MODEL, N, 0.05, otr.L, 20190, range(B))
+    q = orc.build_qp_batch(MODEL, otr, N, 0.05, x0, xr, xl, ul)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = [dev(q[k]) for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")]
+    res = {}
+    for k in range(0, K + 1):
+        o = fm.qp_solve_batch_device(*args, options=fm.default_opts(polish=0, max_iter=k), want_lambda=True, want_aux=True)
+        torch.cuda.synchronize()
+        for nm in ("x", "lam", "fval", "exitflag", "iter", "kkt"):
+            res["%s_%d" % (nm, k)] = o[nm].cpu().numpy()
+    np.savez(out, **res)
+
+
+def main():
+    if sys.argv[1] == "child":
+        return child(sys.argv[2])
+    outs = []
+    for i, lib in enumerate(sys.argv[2:4]):
+        out = "/tmp/frag_iter_%d.npz" % i
+        env = dict(os.environ, FSAEMPC_LIB=os.path.abspath(lib))
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "child", out], env=env)
+        outs.append(np.load(out))
+    a, b = outs
+    for k in range(0, K + 1):
+        dx = np.abs(a["x_%d" % k] - b["x_%d" % k]); dl = np.abs(a["lam_%d" % k] - b["lam_%d" % k])
+        print("max_iter %d: |dx| max %.3e (at var %s)  |dlam| max %.3e (at %s)  |x| %.2e |lam| %.2e  flags %s / %s  kkt %.2e / %.2e" % (
+            k, dx.max(), np.argmax(dx, axis=1)[:4], dl.max(), np.argmax(dl, axis=1)[:4], np.abs(a["x_%d" % k]).max(), np.abs(a["lam_%d" % k]).max(),
+            a["exitflag_%d" % k][:4], b["exitflag_%d" % k][:4], a["kkt_%d" % k].max(), b["kkt_%d" % k].max()), flush=True)
+        if k == int(os.environ.get('FRAG_SHOW', '1')):
+            np.set_printoptions(linewidth=200, precision=3)
+            print(" instance 0 dx by variable:\n", dx[0]); print(" instance 0 dlam (bounds then rows):\n", dl[0])
+
+
+if __name__ == "__main__":
+    main()
