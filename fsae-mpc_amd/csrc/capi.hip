@@ -113,27 +113,87 @@ int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc, const double* H, const d
   if (rc == 0) rc = fsaempc_qp_solve_batch_device(desc, dH, dg, m ? dA : nullptr, dlb, dub, m ? dlbA : nullptr, m ? dubA : nullptr, opts,
                                                   dx, dfv, dfl, dit, dlam, dws, wsb, nullptr);
   if (rc == 0) { e = hipDeviceSynchronize(); if (e != hipSuccess) rc = hipfail(e, "solve"); }
-  if (rc == 0) {
-    (void)hipMemcpy(x, dx, szg * sizeof(double), hipMemcpyDeviceToHost);
-    if (fval) (void)hipMemcpy(fval, dfv, B * sizeof(double), hipMemcpyDeviceToHost);
-    if (exitflag) (void)hipMemcpy(exitflag, dfl, B * sizeof(int), hipMemcpyDeviceToHost);
-    if (iter) (void)hipMemcpy(iter, dit, B * sizeof(int), hipMemcpyDeviceToHost);
-    if (lambda) (void)hipMemcpy(lambda, dlam, szl * sizeof(double), hipMemcpyDeviceToHost);
-  }
+#define BK(dst, src, bytes) do { if (rc == 0 && (dst)) { e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hipfail(e, "hipMemcpy D2H"); } } while (0)
+  BK(x, dx, szg * sizeof(double)); BK(fval, dfv, B * sizeof(double)); BK(exitflag, dfl, B * sizeof(int)); BK(iter, dit, B * sizeof(int));
+  BK(lambda, dlam, szl * sizeof(double));
+#undef BK
   (void)hipFree(dev);
   return rc;
 }
 
 // ---- qpOASES_sequence handles (qpOASES_sequence.m:23-78) ----
+// A handle owns device copies of H and A (uploaded by 'i' / 'm' only), the solver workspace and the per-call vectors (grown to
+// the largest k seen), so a hot start moves (3 nV + 2 nC) k doubles to the device and the results back -- no allocation, no
+// matrix upload.  Every solve is a cold interior-point solve; the handle also remembers the working set of its last solve
+// (first column) for the 'e' call.
 namespace {
-struct SeqQP { int nV = 0, nC = 0; std::vector<double> H, A; bool used = false; };
+struct SeqQP {
+  int nV = 0, nC = 0, kcap = 0;
+  bool used = false;
+  double *dH = nullptr, *dA = nullptr, *dvec = nullptr; void* dws = nullptr; long long wsb = 0;
+  std::vector<signed char> wsB, wsC;   // -1 lower / 0 inactive / +1 upper, qpOASES.m:52-62 encoding
+  void release() {
+    (void)hipFree(dH); (void)hipFree(dA); (void)hipFree(dvec); (void)hipFree(dws);
+    dH = dA = dvec = nullptr; dws = nullptr; kcap = 0; wsb = 0; used = false; wsB.clear(); wsC.clear();
+  }
+};
 std::mutex g_seq_mu;
 std::vector<SeqQP> g_seq;   // handle = index + 1 (the MEX gateway also hands out small integers)
 SeqQP* seq_get(int handle) { return (handle >= 1 && handle <= (int)g_seq.size() && g_seq[handle - 1].used) ? &g_seq[handle - 1] : nullptr; }
+int seq_upload_matrices(SeqQP* q, const double* H, const double* A) {
+  const size_t n = q->nV, m = q->nC;
+  for (size_t i = 0; i < n * n; ++i) if (!isfinite(H[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Argument 1 contains 'NaN' or 'Inf' !");
+  for (size_t i = 0; i < m * n; ++i) if (!isfinite(A[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Argument 3 contains 'NaN' or 'Inf' !");
+  hipError_t e;
+  if (!q->dH) { e = hipMalloc((void**)&q->dH, n * n * sizeof(double)); if (e != hipSuccess) return hipfail(e, "hipMalloc"); }
+  if (m && !q->dA) { e = hipMalloc((void**)&q->dA, m * n * sizeof(double)); if (e != hipSuccess) return hipfail(e, "hipMalloc"); }
+  e = hipMemcpy(q->dH, H, n * n * sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) return hipfail(e, "hipMemcpy H2D");
+  if (m) { e = hipMemcpy(q->dA, A, m * n * sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) return hipfail(e, "hipMemcpy H2D"); }
+  return 0;
+}
 int seq_solve(SeqQP* q, const double* g, const double* lb, const double* ub, const double* lbA, const double* ubA, int k,
-              const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter, double* lambda) {
+              const fsaempc_qp_opts* opts, double* x, double* fval, int* exitflag, int* iter, double* lambda, bool remember) {
+  const size_t n = q->nV, m = q->nC, B = k;
+  if (!g || !lb || !ub || !x || (m && (!lbA || !ubA))) return fail(FSAEMPC_ERR_ARG, "null argument");
+  for (size_t i = 0; i < B * n; ++i) if (!isfinite(g[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Argument 2 contains 'NaN' or 'Inf' !");
+  for (size_t i = 0; i < B * n; ++i) if (isnan(lb[i]) || isnan(ub[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): bounds contain 'NaN' !");
+  for (size_t i = 0; i < B * m; ++i) if (isnan(lbA[i]) || isnan(ubA[i])) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): constraint bounds contain 'NaN' !");
   fsaempc_qp_desc d{q->nV, q->nC, k, 1};
-  return fsaempc_qp_solve_batch(&d, q->H.data(), g, q->nC ? q->A.data() : nullptr, lb, ub, lbA, ubA, opts, x, fval, exitflag, iter, lambda);
+  hipError_t e;
+  if (k > q->kcap) {   // grow the per-call buffers: g lb ub lbA ubA x fval lambda (doubles), exitflag iter (ints), workspace
+    (void)hipFree(q->dvec); (void)hipFree(q->dws); q->dvec = nullptr; q->dws = nullptr; q->kcap = 0;
+    const long long wsb = fsaempc_qp_workspace_bytes(&d);
+    if (wsb < 0) return fail((int)wsb, "workspace size");
+    const size_t nd = B * (4 * n + 2 * m + 1 + (n + m)) + B + 16;
+    e = hipMalloc((void**)&q->dvec, nd * sizeof(double)); if (e != hipSuccess) return hipfail(e, "hipMalloc");
+    e = hipMalloc(&q->dws, (size_t)wsb); if (e != hipSuccess) return hipfail(e, "hipMalloc");
+    q->kcap = k; q->wsb = wsb;
+  }
+  double* p = q->dvec;
+  double* dg = p; p += B * n; double* dlb = p; p += B * n; double* dub = p; p += B * n; double* dlbA = p; p += B * m; double* dubA = p; p += B * m;
+  double* dx = p; p += B * n; double* dfv = p; p += B; double* dlam = p; p += B * (n + m);
+  int* dfl = (int*)p; int* dit = dfl + B;
+  int rc = 0;
+#define CP(dst, src, cnt) do { if (rc == 0 && (cnt) > 0) { e = hipMemcpy(dst, src, (cnt) * sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) rc = hipfail(e, "hipMemcpy H2D"); } } while (0)
+  CP(dg, g, B * n); CP(dlb, lb, B * n); CP(dub, ub, B * n); CP(dlbA, lbA, B * m); CP(dubA, ubA, B * m);
+#undef CP
+  if (rc == 0) rc = fsaempc_qp_solve_batch_device(&d, q->dH, dg, m ? q->dA : nullptr, dlb, dub, m ? dlbA : nullptr, m ? dubA : nullptr, opts,
+                                                  dx, dfv, dfl, dit, dlam, q->dws, q->wsb, nullptr);
+  if (rc == 0) { e = hipDeviceSynchronize(); if (e != hipSuccess) rc = hipfail(e, "solve"); }
+  std::vector<double> lam0;
+  if (rc == 0 && remember && !lambda) lam0.resize(n + m);
+#define BK(dst, src, bytes) do { if (rc == 0 && (dst)) { e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hipfail(e, "hipMemcpy D2H"); } } while (0)
+  BK(x, dx, B * n * sizeof(double)); BK(fval, dfv, B * sizeof(double)); BK(exitflag, dfl, B * sizeof(int)); BK(iter, dit, B * sizeof(int));
+  BK(lambda, dlam, B * (n + m) * sizeof(double));
+  if (!lam0.empty()) BK(lam0.data(), dlam, (n + m) * sizeof(double));
+#undef BK
+  if (rc == 0 && remember) {   // working set of the first column: a side is in it iff its multiplier is non-zero (qpOASES.m:52-62)
+    const double* l = lambda ? lambda : lam0.data();
+    q->wsB.assign(n, 0); q->wsC.assign(m, 0);
+    for (size_t i = 0; i < n; ++i) q->wsB[i] = l[i] > 0 ? -1 : (l[i] < 0 ? 1 : 0);
+    for (size_t i = 0; i < m; ++i) q->wsC[i] = l[n + i] > 0 ? -1 : (l[n + i] < 0 ? 1 : 0);
+  }
+  return rc;
 }
 }  // namespace
 
@@ -141,15 +201,17 @@ int fsaempc_seq_init(int nV, int nC, const double* H, const double* g, const dou
                      const double* lbA, const double* ubA, int k, const fsaempc_qp_opts* opts, int* handle,
                      double* x, double* fval, int* exitflag, int* iter, double* lambda) {
   if (!handle || !H || nV <= 0 || nC < 0 || k <= 0 || (nC > 0 && !A)) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'i'");
+  if (nV > FSAEMPC_MAX_NV) return fail(FSAEMPC_ERR_DIM, "nV exceeds FSAEMPC_MAX_NV");
   std::lock_guard<std::mutex> lk(g_seq_mu);
   int idx = -1;
   for (size_t i = 0; i < g_seq.size(); ++i) if (!g_seq[i].used) { idx = (int)i; break; }
   if (idx < 0) { g_seq.emplace_back(); idx = (int)g_seq.size() - 1; }
   SeqQP& q = g_seq[idx];
-  q.nV = nV; q.nC = nC; q.H.assign(H, H + (size_t)nV * nV); q.A.assign(A ? A : H, (A ? A : H) + (size_t)nC * nV); q.used = true;
+  q.nV = nV; q.nC = nC; q.used = true;
   *handle = idx + 1;
-  int rc = seq_solve(&q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda);
-  if (rc != 0) { q.used = false; *handle = 0; }
+  int rc = seq_upload_matrices(&q, H, A);
+  if (rc == 0) rc = seq_solve(&q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda, true);
+  if (rc != 0) { q.release(); *handle = 0; }
   return rc;
 }
 int fsaempc_seq_hotstart(int handle, int nV, int nC, const double* g, const double* lb, const double* ub, const double* lbA,
@@ -158,7 +220,8 @@ int fsaempc_seq_hotstart(int handle, int nV, int nC, const double* g, const doub
   SeqQP* q = seq_get(handle);
   if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");
   if (nV != q->nV || nC != q->nC) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): QP dimensions must be constant during a sequence!");
-  return seq_solve(q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda);
+  if (k <= 0) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'h'");
+  return seq_solve(q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda, true);
 }
 int fsaempc_seq_hotstart_matrices(int handle, int nV, int nC, const double* H, const double* g, const double* A, const double* lb,
                                   const double* ub, const double* lbA, const double* ubA, int k, const fsaempc_qp_opts* opts,
@@ -167,16 +230,47 @@ int fsaempc_seq_hotstart_matrices(int handle, int nV, int nC, const double* H, c
   SeqQP* q = seq_get(handle);
   if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");
   if (nV != q->nV || nC != q->nC) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): QP dimensions must be constant during a sequence!");
-  if (!H || (nC > 0 && !A)) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'm'");
-  q->H.assign(H, H + (size_t)nV * nV);
-  if (nC) q->A.assign(A, A + (size_t)nC * nV);
-  return seq_solve(q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda);
+  if (!H || (nC > 0 && !A) || k <= 0) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'm'");
+  int rc = seq_upload_matrices(q, H, A);
+  if (rc != 0) return rc;
+  return seq_solve(q, g, lb, ub, lbA, ubA, k, opts, x, fval, exitflag, iter, lambda, true);
+}
+// 'e' (qpOASES_sequence.m:64-72): the equality-constrained QP fixed by the working set of the handle's last solve -- sides in the
+// working set hold with equality at the new bound values, every other bound / row is dropped ("might be violated").  Does not
+// alter the handle.  Solved by the same kernel with lb = ub on the active sides and no bound elsewhere.
+int fsaempc_seq_equality(int handle, int nV, int nC, const double* g, const double* lb, const double* ub, const double* lbA,
+                         const double* ubA, int k, const fsaempc_qp_opts* opts, double* x, double* lambda, int* workingSetB, int* workingSetC) {
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  SeqQP* q = seq_get(handle);
+  if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");
+  if (nV != q->nV || nC != q->nC) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): QP dimensions must be constant during a sequence!");
+  if (k <= 0 || !g || !lb || !ub || !x || (nC && (!lbA || !ubA))) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): invalid arguments to 'e'");
+  if ((int)q->wsB.size() != nV) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): no working set yet (solve with 'i' / 'h' / 'm' first)");
+  const size_t n = nV, m = nC, B = k;
+  std::vector<double> l2(B * n), u2(B * n), lA2(B * m), uA2(B * m);
+  for (size_t j = 0; j < B; ++j) {
+    for (size_t i = 0; i < n; ++i) {
+      const int w = q->wsB[i]; const double v = w < 0 ? lb[j * n + i] : ub[j * n + i];
+      l2[j * n + i] = w ? v : -INFINITY; u2[j * n + i] = w ? v : INFINITY;
+    }
+    for (size_t i = 0; i < m; ++i) {
+      const int w = q->wsC[i]; const double v = w < 0 ? lbA[j * m + i] : ubA[j * m + i];
+      lA2[j * m + i] = w ? v : -INFINITY; uA2[j * m + i] = w ? v : INFINITY;
+    }
+  }
+  std::vector<int> fl(B), it(B);
+  int rc = seq_solve(q, g, l2.data(), u2.data(), m ? lA2.data() : nullptr, m ? uA2.data() : nullptr, k, opts, x, nullptr, fl.data(), it.data(), lambda, false);
+  if (rc != 0) return rc;
+  if (workingSetB) for (size_t i = 0; i < n; ++i) workingSetB[i] = q->wsB[i];
+  if (workingSetC) for (size_t i = 0; i < m; ++i) workingSetC[i] = q->wsC[i];
+  for (size_t j = 0; j < B; ++j) if (fl[j] != 0) return fail(FSAEMPC_ERR_SOLVER, "ERROR (qpOASES): equality-constrained QP could not be solved (working set linearly dependent or infeasible)");
+  return 0;
 }
 int fsaempc_seq_cleanup(int handle) {
   std::lock_guard<std::mutex> lk(g_seq_mu);
   SeqQP* q = seq_get(handle);
   if (!q) return fail(FSAEMPC_ERR_ARG, "ERROR (qpOASES): Invalid handle to QP instance!");   // what main.m:193 would hit with QP == 0
-  q->used = false; q->H.clear(); q->A.clear();
+  q->release();
   return 0;
 }
 

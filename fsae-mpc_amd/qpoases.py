@@ -119,8 +119,9 @@ def qpOASES_sequence(cmd, *args, options=None):
       [QP,x,fval,exitflag,iter,lambda] = qpOASES_sequence('i', H,g,A,lb,ub,lbA,ubA)     (:23)
       [x,fval,exitflag,iter,lambda]    = qpOASES_sequence('h', QP, g,lb,ub,lbA,ubA)     (:39)
       [x,fval,exitflag,iter,lambda]    = qpOASES_sequence('m', QP, H,g,A,lb,ub,lbA,ubA) (:51)
+      [x,lambda,workingSetB,workingSetC] = qpOASES_sequence('e', QP, g,lb,ub,lbA,ubA)   (:64)
                                          qpOASES_sequence('c', QP)                      (:76)
-    The handle remembers the dimensions (and H, A for 'h'); every call is a cold solve in this round."""
+    The handle owns device copies of H and A, the workspace and the per-call vectors; every call is a cold solve."""
     L = lib()
     opts = options if options is not None else default_opts()
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
@@ -155,6 +156,15 @@ def qpOASES_sequence(cmd, *args, options=None):
                                                  p(f(lbA)), p(f(ubA)), 1, C.byref(opts), p(x), p(fv), p(fl), p(it), p(lam))
         check(rc, "qpOASES_sequence('%s')" % cmd)
         return x, float(fv[0]), int(fl[0]), int(it[0]), lam
+    if cmd == "e":
+        QP = int(args[0])
+        nV, nC = _SEQ_DIMS.get(QP, (1, 0))
+        g, lb, ub, lbA, ubA = args[1:]
+        x, lam = np.zeros(nV), np.zeros(nV + nC)
+        wb, wc = np.zeros(nV, dtype=np.int32), np.zeros(max(nC, 1), dtype=np.int32)
+        check(L.fsaempc_seq_equality(QP, nV, nC, p(f(g)), p(f(lb)), p(f(ub)), p(f(lbA)), p(f(ubA)), 1, C.byref(opts), p(x), p(lam), p(wb), p(wc)),
+              "qpOASES_sequence('e')")
+        return x, lam, wb, wc[:nC]
     if cmd == "c":
         check(L.fsaempc_seq_cleanup(int(args[0])), "qpOASES_sequence('c')")
         _SEQ_DIMS.pop(int(args[0]), None)

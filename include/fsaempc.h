@@ -28,6 +28,7 @@ extern "C" {
 #define FSAEMPC_ERR_HIP      (-3)  /* HIP runtime error (see fsaempc_last_error) */
 #define FSAEMPC_ERR_NODEVICE (-4)  /* no gfx950 device / code object not loadable: there is NO CPU fallback */
 #define FSAEMPC_ERR_WORKSPACE (-5) /* workspace too small */
+#define FSAEMPC_ERR_SOLVER   (-6)  /* a call whose contract is "solve or fail" could not solve (fsaempc_seq_equality) */
 
 #define FSAEMPC_MAX_NV 196   /* 12 column tiles of 16 + up to 4 border columns (config 5: dynamic N = 80, nV = 164) */
 
@@ -112,9 +113,12 @@ int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc,
 /* ---- qpOASES_sequence: handle-based solves of a sequence of QPs -------------------------------
  * Replaces optimizers/matlab/qpOASES/qpOASES_sequence.m:23 ('i'), :39 ('h'), :51 ('m'), :76 ('c')
  * (commented call sites ltvmpc_kinetmatic_curvilinear.m:44-50, live cleanup main.m:193).  Host pointers,
- * one QP per call (k columns of g/lb/ub/lbA/ubA => k QPs, as in qpOASES.m:65-67).  The handle keeps H and A
- * resident on the device between calls.  This round every call is a cold interior-point solve (the results are
- * those of qpOASES hot starts; the previous iterate is not yet used as a warm start).
+ * one QP per call (k columns of g/lb/ub/lbA/ubA => k QPs, as in qpOASES.m:65-67).  The handle owns device copies of H and
+ * A (uploaded by 'i' and 'm' only), the solver workspace and the per-call vectors, so a hot start transfers (3 nV + 2 nC) k
+ * doubles and the results, nothing else.  Every call is a COLD interior-point solve: same results as a qpOASES hot start, but
+ * the previous iterate is not used as a starting point (an interior-point method gains little from it).
+ * fsaempc_seq_equality is qpOASES_sequence.m:64 ('e'): the equality-constrained QP fixed by the working set of the handle's
+ * last 'i'/'h'/'m' solve (first column); it returns FSAEMPC_ERR_SOLVER when that QP has no solution and leaves the handle as is.
  * Errors mirror the gateway: unknown handle => FSAEMPC_ERR_ARG "Invalid handle to QP instance!", changed
  * dimensions => FSAEMPC_ERR_ARG "QP dimensions must be constant during a sequence!". */
 int fsaempc_seq_init(int nV, int nC, const double* H, const double* g, const double* A,
@@ -128,6 +132,9 @@ int fsaempc_seq_hotstart_matrices(int handle, int nV, int nC, const double* H, c
                                   const double* lb, const double* ub, const double* lbA, const double* ubA, int k,
                                   const fsaempc_qp_opts* opts,
                                   double* x, double* fval, int* exitflag, int* iter, double* lambda);  /* 'm' */
+int fsaempc_seq_equality(int handle, int nV, int nC, const double* g, const double* lb, const double* ub,
+                         const double* lbA, const double* ubA, int k, const fsaempc_qp_opts* opts,
+                         double* x, double* lambda, int* workingSetB, int* workingSetC);        /* 'e' */
 int fsaempc_seq_cleanup(int handle);                                                         /* 'c' */
 
 /* ---- LTV-MPC step (QP construction + solve + post-solve) ---------------------------------- */

@@ -1,13 +1,25 @@
 // mex/qpOASES.cpp -- MEX gateway that makes libfsaempc.so a drop-in for the reference's
 //     [x,fval,exitflag,iter,lambda,auxOutput] = qpOASES(H,g,A,lb,ub,lbA,ubA{,options})
 // (optimizers/matlab/qpOASES/qpOASES.m:22-23; bounds-only form :34-35; k-column form :65-67).
-// NOT compiled in this repo: MATLAB / mex.h do not exist in the build container or on the GPU box.
+// Not BUILT in this repo (no MATLAB here); type-checked against tests/stub_mex/mex.h by tests/test_abi_cpu.py.
 // Build on a MATLAB host:   mex -I<repo>/include mex/qpOASES.cpp -L<repo>/fsae-mpc_amd/lib -lfsaempc
 #include <cmath>
 #include <cstring>
 #include <vector>
 #include "mex.h"
 #include "fsaempc.h"
+
+// options struct of qpOASES_options.m -> fsaempc_qp_opts: maxIter (:41, -1 = automatic) bounds the iterations,
+// terminationTolerance (:71, relative) is the KKT tolerance; every other field steers the active-set homotopy and has no
+// counterpart in an interior-point method (ignored, as documented in INTEGRATION.md)
+static void map_options(const mxArray* o, fsaempc_qp_opts* q) {
+  fsaempc_qp_default_opts(q);
+  if (!o || !mxIsStruct(o)) return;
+  const mxArray* f = mxGetField(o, 0, "maxIter");
+  if (f && !mxIsEmpty(f) && mxGetScalar(f) > 0) q->max_iter = (int)mxGetScalar(f);
+  f = mxGetField(o, 0, "terminationTolerance");
+  if (f && !mxIsEmpty(f) && mxGetScalar(f) > 0) { q->tol = mxGetScalar(f) > 1e-12 ? mxGetScalar(f) : 1e-12; if (q->tol_loose < q->tol) q->tol_loose = q->tol; }
+}
 
 static void dense(const mxArray* a, std::vector<double>& out) {  // qpOASES.m:30: H and A may be sparse
   const mwSize m = mxGetM(a), n = mxGetN(a);
@@ -24,9 +36,12 @@ static void dense(const mxArray* a, std::vector<double>& out) {  // qpOASES.m:30
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (nrhs < 4) mexErrMsgTxt("ERROR (qpOASES): Invalid number of input arguments!");
-  for (int i = 0; i < (nrhs < 7 ? nrhs : 7); ++i)
-    if (!mxIsDouble(prhs[i]) || mxIsComplex(prhs[i])) mexErrMsgTxt("ERROR (qpOASES): All data has to be provided in double precision!");
-  const bool general = nrhs >= 7 && !mxIsStruct(prhs[4]);   // (H,g,A,lb,ub,lbA,ubA) vs (H,g,lb,ub)
+  const bool general = nrhs >= 7 && !mxIsStruct(prhs[4]);   // (H,g,A,lb,ub,lbA,ubA{,options}) vs (H,g,lb,ub{,options})
+  const int ndata = general ? 7 : 4;                        // the numeric arguments; what follows is the options struct
+  for (int i = 0; i < ndata; ++i)
+    if (!mxIsEmpty(prhs[i]) && (!mxIsDouble(prhs[i]) || mxIsComplex(prhs[i]))) mexErrMsgTxt("ERROR (qpOASES): All data has to be provided in double precision!");
+  fsaempc_qp_opts opts;
+  map_options(nrhs > ndata ? prhs[ndata] : nullptr, &opts);
   const mxArray *H = prhs[0], *g = prhs[1];
   const mxArray *A = general ? prhs[2] : nullptr, *lb = prhs[general ? 3 : 2], *ub = prhs[general ? 4 : 3];
   const mxArray *lbA = general ? prhs[5] : nullptr, *ubA = general ? prhs[6] : nullptr;
@@ -51,7 +66,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   std::vector<int> flag(k), iter(k);
   fsaempc_qp_desc d{nV, nC, k, 1};   // k QPs sharing H and A
   const int rc = fsaempc_qp_solve_batch(&d, Hd.data(), gv.data(), general ? Ad.data() : nullptr, lbv.data(), ubv.data(),
-                                        general ? lbAv.data() : nullptr, general ? ubAv.data() : nullptr, nullptr,
+                                        general ? lbAv.data() : nullptr, general ? ubAv.data() : nullptr, &opts,
                                         mxGetPr(plhs[0]), fval.data(), flag.data(), iter.data(), lam.data());
   if (rc != 0) mexErrMsgTxt(fsaempc_last_error());   // argument errors are MEX errors, solver outcomes are exit flags
   auto out = [&](int i, int rows, auto&& get) {

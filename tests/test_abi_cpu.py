@@ -121,3 +121,12 @@ def test_bench_self_starts_two_ranks_over_gloo():
     assert out["config"]["gathered_rows"] == 74 and out["config"]["gather_ok"]
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline"):
         assert k in out
+
+
+@pytest.mark.parametrize("src", ["qpOASES.cpp", "qpOASES_sequence.cpp"])
+def test_mex_gateways_compile(src):
+    """the MEX gateways type-check against a stand-in mex.h and the real include/fsaempc.h (no MATLAB in this image)"""
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "stub_mex"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "mex", src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -320,6 +320,33 @@ def test_sequence_api(fm, orc, otrack):
         fm.qpOASES_sequence("c", QP)
 
 
+def test_sequence_equality_call(fm):
+    """qpOASES_sequence('e') (qpOASES_sequence.m:64): the equality-constrained QP fixed by the working set of the last solve,
+    checked against a dense KKT solve with numpy (independent of the solver)."""
+    rng = np.random.default_rng(7)
+    n, m = 8, 4
+    Q = rng.normal(size=(n, n)); H = Q @ Q.T + np.eye(n); g = rng.normal(size=n) * 3
+    A = rng.normal(size=(m, n))
+    lb, ub = -0.3 * np.ones(n), 0.3 * np.ones(n)
+    lbA, ubA = -0.2 * np.ones(m), 0.2 * np.ones(m)
+    QP, x, f, fl, it, lam = fm.qpOASES_sequence("i", H, g, A, lb, ub, lbA, ubA)
+    assert fl == 0
+    wB = np.where(lam[:n] > 0, -1, np.where(lam[:n] < 0, 1, 0)); wC = np.where(lam[n:] > 0, -1, np.where(lam[n:] < 0, 1, 0))
+    assert (wB != 0).sum() + (wC != 0).sum() >= 2            # the case has active sides
+    g2 = g * 1.02                                            # new gradient, same working set
+    xe, lame, wb, wc = fm.qpOASES_sequence("e", QP, g2, lb, ub, lbA, ubA)
+    assert np.array_equal(wb, wB) and np.array_equal(wc, wC)
+    rows = [np.eye(n)[i] for i in range(n) if wB[i]] + [A[i] for i in range(m) if wC[i]]
+    rhs = [(lb[i] if wB[i] < 0 else ub[i]) for i in range(n) if wB[i]] + [(lbA[i] if wC[i] < 0 else ubA[i]) for i in range(m) if wC[i]]
+    Aw = np.array(rows); k = len(rows)
+    K = np.block([[H, Aw.T], [Aw, np.zeros((k, k))]])
+    sol = np.linalg.solve(K, np.concatenate([-g2, np.array(rhs)]))
+    assert np.abs(xe - sol[:n]).max() <= 1e-6 * max(1.0, np.abs(sol[:n]).max())
+    xq, *_ = fm.qpOASES_sequence("h", QP, g2, lb, ub, lbA, ubA)      # 'e' did not alter the handle; 'h' still works
+    assert np.abs(xq - xe).max() <= 1e-5                              # same active set for this small change
+    fm.qpOASES_sequence("c", QP)
+
+
 def test_edge_cases(fm, torch_):
     torch = torch_
     # nV = 1, nC = 0 ; empty batch ; random SPD data up to nV = 196 (FSAEMPC_MAX_NV: 12 tiles + 4 border columns) ; ragged tile sizes
