@@ -133,10 +133,12 @@ def test_known_answer_qps(orc):
     assert fl == 0 and np.allclose(x, [3, 0], atol=1e-6)
 
 
-@pytest.mark.parametrize("model,N", [(0, 5), (0, 10), (1, 5)])
-def test_solution_vs_scipy(orc, otrack, model, N):
+@pytest.mark.parametrize("model,N,inst", [(0, 5, 3), (0, 10, 3), (1, 5, 3), (0, 20, 3), (1, 10, 3), (1, 20, 5)])
+def test_solution_vs_scipy(orc, otrack, model, N, inst):
+    """Independent solver (scipy trust-constr, a different algorithm and code base) on LTV-MPC QPs up to nV = 44, nC = 400: the
+    oracle's refined solution is the same point to 1e-6 in x (measured: <= 4e-8) and 1e-8 in the objective."""
     from scipy.optimize import Bounds, LinearConstraint, minimize
-    x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, [3])
+    x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, [inst])
     q = orc.build_qp(model, otrack, N, 0.05, x0[0], xr[0].T, xl[0].T, ul[0].T)
     H, g, A = q["H"], q["g"], q["A"]
     x, f, fl, it, lam = orc.qp_solve(H, g, A, q["lb"], q["ub"], q["lbA"], q["ubA"])
@@ -144,9 +146,9 @@ def test_solution_vs_scipy(orc, otrack, model, N):
     lbA = np.where(q["lbA"] < -1e9, -np.inf, q["lbA"]); ubA = np.where(q["ubA"] > 1e9, np.inf, q["ubA"])
     res = minimize(lambda z: 0.5 * z @ H @ z + g @ z, np.clip(x * 0, q["lb"], np.minimum(q["ub"], 1e3)), jac=lambda z: H @ z + g, hess=lambda z: H,
                    method="trust-constr", bounds=Bounds(q["lb"], q["ub"]), constraints=[LinearConstraint(A, lbA, ubA)],
-                   options=dict(gtol=1e-10, xtol=1e-12, barrier_tol=1e-12, maxiter=3000))
-    assert abs(res.fun - f) <= 1e-5 * max(1.0, abs(f))
-    assert np.max(np.abs(res.x - x)) <= 2e-3 * max(1.0, np.max(np.abs(x)))
+                   options=dict(gtol=1e-10, xtol=1e-12, barrier_tol=1e-12, maxiter=5000))
+    assert abs(res.fun - f) <= 1e-8 * max(1.0, abs(f))
+    assert np.max(np.abs(res.x - x)) <= 1e-6 * max(1.0, np.max(np.abs(x)))
 
 
 @pytest.mark.parametrize("path", golden_files())
