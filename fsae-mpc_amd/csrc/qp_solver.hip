@@ -70,26 +70,33 @@ DEVINL double grp16_min(double v) {
   v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, dpp_f64<0x4E>(v)); v = fmin(v, dpp_f64<0x141>(v)); v = fmin(v, dpp_f64<0x140>(v));
   return v;
 }
-// whole-wave reductions: DPP within the four 16-lane rows, then four scalar lane reads (no LDS round trips)
-DEVINL double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// Exchange between the four 16-lane rows of a wave with the gfx950 lane-swap instructions (VALU speed; the ds_bpermute
+// round trips of __shfl_xor cost ~100 cycles each and a wave reduction needed twelve of them):
+//   v_permlane16_swap a, b : a.row1 <-> b.row0, a.row3 <-> b.row2     v_permlane32_swap a, b : a.rows23 <-> b.rows01
+// with a = b = v on entry the two results are (row0,row0,row2,row2) / (row1,row1,row3,row3) resp. (rows01 x2) / (rows23 x2).
+struct RowPair { double a, b; };
+DEVINL RowPair rows_xor16(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return {__hiloint2double(h[0], l[0]), __hiloint2double(h[1], l[1])};
 }
-DEVINL double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+DEVINL RowPair rows_xor32(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return {__hiloint2double(h[0], l[0]), __hiloint2double(h[1], l[1])};
 }
-DEVINL double wave_min(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-  return v;
+DEVINL double q_sum(double v) {  // sum over the 4 lane groups (same l&15); every lane gets the total
+  RowPair r = rows_xor16(v); v = r.a + r.b;
+  r = rows_xor32(v); return r.a + r.b;
 }
-DEVINL double q_sum(double v) {  // sum over the 4 lane groups (same l&15)
-  v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-  return v;
-}
+DEVINL double q_max(double v) { RowPair r = rows_xor16(v); v = fmax(r.a, r.b); r = rows_xor32(v); return fmax(r.a, r.b); }
+DEVINL double q_min(double v) { RowPair r = rows_xor16(v); v = fmin(r.a, r.b); r = rows_xor32(v); return fmin(r.a, r.b); }
+// whole-wave reductions: DPP within the four 16-lane rows, lane swaps across them (no LDS round trips)
+DEVINL double wave_sum(double v) { return q_sum(grp16_sum(v)); }
+DEVINL double wave_max(double v) { return q_max(grp16_max(v)); }
+DEVINL double wave_min(double v) { return q_min(grp16_min(v)); }
 
 template <int T> struct Tri {
   static constexpr int NT = T * (T + 1) / 2;
@@ -776,12 +783,12 @@ DEVINL int diag_factor(const Ctx& k, v4d& Ud, v4d& Yk, v4d& rk, double floor_abs
 
 // Blocked Cholesky of acc (upper tiles) in place.  Yt[K] = U_KK^-T and Wt[K] = U_KK^-1 are kept for the solves;
 // rh rides along and leaves as y = U^-T b.
-template <int T, int K> struct FactorStep {
+template <int T, int K, bool RHS> struct FactorStep {
   static DEVINL int run(const Ctx& k, v4d* acc, double* YL, v4d* rh, double floor_abs) {
-    v4d Yk;
+    v4d Yk, none = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int p = 0; p < 4; ++p) Yk[p] = (k.q + 4 * p == k.c) ? 1.0 : 0.0;
-    int bad = diag_factor(k, acc[Tri<T>::idx(K, K)], Yk, rh[K], floor_abs);
+    int bad = diag_factor(k, acc[Tri<T>::idx(K, K)], Yk, RHS ? rh[K] : none, floor_abs);
     tile_store(k, YL + K * 272, Yk);          // U_KK^-T stays in LDS for the solves of this iteration
     WAVE_SYNC();
     const v4d Wk = tile_load_t(k, YL + K * 272);   // U_KK^-1
@@ -792,16 +799,21 @@ template <int T, int K> struct FactorStep {
       const v4d& UKI = acc[Tri<T>::idx(K, I)];
 #pragma unroll
       for (int Jt = I; Jt < T; ++Jt) mfma4_sub<T>(UKI, acc[Tri<T>::idx(K, Jt)], acc[Tri<T>::idx(I, Jt)]);
-      mfma4_sub<T>(UKI, rh[K], rh[I]);
+      if (RHS) mfma4_sub<T>(UKI, rh[K], rh[I]);
     }
-    return bad | FactorStep<T, K + 1>::run(k, acc, YL, rh, floor_abs);
+    return bad | FactorStep<T, K + 1, RHS>::run(k, acc, YL, rh, floor_abs);
   }
 };
-template <int T> struct FactorStep<T, T> {
+template <int T, bool RHS> struct FactorStep<T, T, RHS> {
   static DEVINL int run(const Ctx&, v4d*, double*, v4d*, double) { return 0; }
 };
+// with right-hand sides riding along as a tile column (they leave as y = U^-T b) ...
 template <int T> DEVINL int reg_factor(const Ctx& k, v4d* acc, double* YL, v4d* rh, double floor_abs) {
-  return FactorStep<T, 0>::run(k, acc, YL, rh, floor_abs);
+  return FactorStep<T, 0, true>::run(k, acc, YL, rh, floor_abs);
+}
+// ... or the factor alone (the solves then run on the VALU: vec_forward / vec_backward)
+template <int T> DEVINL int reg_factor_only(const Ctx& k, v4d* acc, double* YL, double floor_abs) {
+  return FactorStep<T, 0, false>::run(k, acc, YL, nullptr, floor_abs);
 }
 
 // forward solve U'y = b on a fresh right-hand-side tile column: y_K = U_KK^-T (b_K - sum_{I<K} U_IK' y_I)
@@ -825,6 +837,63 @@ template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const do
     }
     rh[K] = mfma4_new(tile_load(k, YL + K * 272), rh[K]);                    // (U_KK^-T)' = U_KK^-1
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangular solves of ONE right-hand side on the VALU.  A 16-wide right-hand-side tile column on the matrix cores spends 16x
+// the work on a single vector and chains four dependent 64-cycle MFMAs per tile; the same products here are four FMAs per tile
+// plus DPP / lane-swap reductions, and the backward sweep needs no tile transposes through LDS.
+// Vector layouts: "by column": lane (c, .) holds v[c];  "by row": reg p of lane (., q) holds v[q + 4p]  (each replicated
+// over the other lane coordinate).  Tiles are in accumulator layout: lane (c,q), reg p <-> X[q+4p][c].
+// ---------------------------------------------------------------------------------------------
+// U'y = b:  t_K = b_K - sum_{I<K} U_IK' y_I (by column),  y_K = U_KK^-T t_K (by row).  B: LDS vector (core part).
+template <int T> DEVINL void vec_forward(const Ctx& k, const v4d* acc, const double* YL, const double* B, double (&y)[T][4]) {
+#pragma unroll
+  for (int K = 0; K < T; ++K) {
+    double s = 0.0;
+#pragma unroll
+    for (int I = 0; I < K; ++I)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s = fma(acc[Tri<T>::idx(I, K)][p], y[I][p], s);   // this lane group's rows of (U_IK' y_I)[c]
+    const double t = B[16 * K + k.c] - (K > 0 ? q_sum(s) : 0.0);
+    const v4d Yt = tile_load(k, YL + K * 272);                                        // U_KK^-T
+#pragma unroll
+    for (int p = 0; p < 4; ++p) y[K][p] = grp16_sum(Yt[p] * t);                       // y_K[q+4p] = sum_c Y[q+4p][c] t[c]
+  }
+}
+// U x = y:  w_K = y_K - sum_{J>K} U_KJ x_J (by row),  x_K = U_KK^-1 w_K = (U_KK^-T)' w_K (by column) -> X (LDS vector, core part)
+template <int T> DEVINL void vec_backward(const Ctx& k, const v4d* acc, const double* YL, const double (&y)[T][4], double* X) {
+  double x[T];
+#pragma unroll
+  for (int K = T - 1; K >= 0; --K) {
+    const v4d Yt = tile_load(k, YL + K * 272);
+    double s2 = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      double s = 0.0;
+#pragma unroll
+      for (int J = K + 1; J < T; ++J) s = fma(acc[Tri<T>::idx(K, J)][p], x[J], s);    // this lane's column of (U_KJ x_J)[q+4p]
+      const double w = y[K][p] - (K < T - 1 ? grp16_sum(s) : 0.0);
+      s2 = fma(Yt[p], w, s2);
+    }
+    x[K] = q_sum(s2);
+    if (k.q == 0) X[16 * K + k.c] = x[K];
+  }
+}
+// by-row vector <-> LDS vector
+template <int T> DEVINL void vec_rows_store(const Ctx& k, const double (&y)[T][4], double* V) {
+  if (k.c == 0) {
+#pragma unroll
+    for (int K = 0; K < T; ++K)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) V[16 * K + k.q + 4 * p] = y[K][p];
+  }
+}
+template <int T> DEVINL void vec_rows_load(const Ctx& k, const double* V, double (&y)[T][4]) {
+#pragma unroll
+  for (int K = 0; K < T; ++K)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) y[K][p] = V[16 * K + k.q + 4 * p];
 }
 
 // right-hand sides: NS LDS vectors <-> slots 0..NS-1 (= lane column c) of the rhs tile column (core rows only)
@@ -1135,15 +1204,31 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1[i]; P.dump[n * n + n + i] = P2[i]; P.dump[n * n + 2 * n + i] = P3[i]; P.dump[n * n + 3 * n + i] = HX[i]; }
     }
 #endif
+#ifdef QP_MFMA_SOLVES   // round-1 form: right-hand sides as a 16-wide tile column on the matrix cores (kept for A/B runs)
     {
       const double* vin[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
       rhs_load<T, 2 + NB>(k, rh, vin);
     }
     int fbad = reg_factor<T>(k, acc, YL, rh, 1e-30 * dmax);
-    if (NB > 0) {   // bordered factor: u_e = U^-T m_e came out of the forward sweep; S = M_bb - u'u is factorised as scalars
+#else
+    int fbad = reg_factor_only<T>(k, acc, YL, 1e-30 * dmax);
+    WAVE_SYNC();
+#endif
+    if (NB > 0) {   // bordered factor: u_e = U^-T m_e; S = M_bb - u'u is factorised as scalars
+#ifdef QP_MFMA_SOLVES
       double* vout[6] = {R1, R2, MB, MB + k.np, MB + 2 * k.np, MB + 3 * k.np};
       rhs_store<T, 2 + NB>(k, rh, vout);
       WAVE_SYNC();
+#else
+#pragma unroll
+      for (int e = 0; e < NB; ++e) {
+        double ue[T][4];
+        vec_forward<T>(k, acc, YL, MB + e * k.np, ue);
+        WAVE_SYNC();
+        vec_rows_store<T>(k, ue, MB + e * k.np);
+      }
+      WAVE_SYNC();
+#endif
       double S[NBB][NBB];
 #pragma unroll
       for (int e = 0; e < NB; ++e)
@@ -1170,6 +1255,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       }
     }
     if (fbad) return 1;
+#ifdef QP_MFMA_SOLVES
     if (NB > 0) {
       border_solve(R1); border_solve(R2);
       const double* vin[2] = {R1, R2};
@@ -1177,22 +1263,39 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }
     reg_backward<T>(k, acc, YL, rh, SCR);
     { double* vout[2] = {R1, R2}; rhs_store<T, 2>(k, rh, vout); }
+#else
+    {
+      double y1[T][4], y2[T][4];
+      vec_forward<T>(k, acc, YL, R1, y1);
+      vec_forward<T>(k, acc, YL, R2, y2);
+      if (NB > 0) {
+        WAVE_SYNC();
+        vec_rows_store<T>(k, y1, R1); vec_rows_store<T>(k, y2, R2);
+        WAVE_SYNC();
+        border_solve(R1); border_solve(R2);
+        vec_rows_load<T>(k, R1, y1); vec_rows_load<T>(k, R2, y2);
+      }
+      WAVE_SYNC();
+      vec_backward<T>(k, acc, YL, y1, R1);
+      vec_backward<T>(k, acc, YL, y2, R2);
+    }
+#endif
     WAVE_SYNC();
     return 0;
   };
-  // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place)
+  // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place), on the VALU
   auto solve1 = [&](double* V) __attribute__((always_inline)) {
-    const double* vin[1] = {V}; double* vout[1] = {V};
-    rhs_load<T, 1>(k, rh, vin);
-    reg_forward<T>(k, acc, YL, rh);
+    double yv[T][4];
+    vec_forward<T>(k, acc, YL, V, yv);
     if (NB > 0) {
-      rhs_store<T, 1>(k, rh, vout);
+      WAVE_SYNC();
+      vec_rows_store<T>(k, yv, V);
       WAVE_SYNC();
       border_solve(V);
-      rhs_load<T, 1>(k, rh, vin);
+      vec_rows_load<T>(k, V, yv);
     }
-    reg_backward<T>(k, acc, YL, rh, SCR);
-    rhs_store<T, 1>(k, rh, vout);
+    WAVE_SYNC();
+    vec_backward<T>(k, acc, YL, yv, V);
   };
 
   STAMP(0);

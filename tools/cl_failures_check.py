@@ -50,7 +50,7 @@ def main():
     from scipy.optimize import Bounds, LinearConstraint, linprog, minimize
     res = {}
     for f, lst in sorted(kept.items()):
-        n_inf = n_feas = n_match = 0; worst = 0.0
+        n_inf = n_feas = n_match = n_err = 0; worst = 0.0
         for e in lst:
             A = e["A"].T                                                    # stored column-major nC x nV
             lbA = np.where(e["lbA"] < -1e9, -np.inf, e["lbA"]); ubA = np.where(e["ubA"] > 1e9, np.inf, e["ubA"])
@@ -61,16 +61,21 @@ def main():
                 n_inf += 1
                 continue
             n_feas += 1
-            if n_feas > 6:                                                   # the independent QP solve takes ~a minute per instance
+            if n_feas > 4:                                                   # the independent QP solve takes ~a minute per instance
                 continue
             H = e["H"].T
-            sol = minimize(lambda z: 0.5 * z @ H @ z + e["g"] @ z, lp.x, jac=lambda z: H @ z + e["g"], hess=lambda z: H, method="trust-constr",
-                           bounds=Bounds(lb, ub), constraints=[LinearConstraint(A, lbA, ubA)], options=dict(gtol=1e-9, xtol=1e-11, barrier_tol=1e-11, maxiter=3000))
+            print("flag %d: independent QP solve %d ..." % (f, n_feas), file=sys.stderr, flush=True)
+            try:
+                    sol = minimize(lambda z: 0.5 * z @ H @ z + e["g"] @ z, lp.x, jac=lambda z: H @ z + e["g"], hess=lambda z: H, method="trust-constr",
+                               bounds=Bounds(lb, ub), constraints=[LinearConstraint(A, lbA, ubA)], options=dict(gtol=1e-9, xtol=1e-11, barrier_tol=1e-11, maxiter=1500))
+            except Exception as ex:                                          # scipy's own numerics gave up on this instance
+                n_err += 1
+                continue
             nz = len(e["z"])
             d = float(np.max(np.abs(sol.x[:nz] - e["z"])) / max(1.0, np.max(np.abs(sol.x))))
             worst = max(worst, d); n_match += d <= 1e-3
         res[str(f)] = {"examined": len(lst), "infeasible_by_HiGHS": n_inf, "feasible": n_feas,
-                       "feasible_solved_independently": min(n_feas, 6), "of_those_kernel_iterate_within_1e-3_of_independent_optimum": int(n_match), "worst_rel_distance_to_independent_optimum": worst}
+                       "feasible_solved_independently": min(n_feas, 4) - n_err, "independent_solver_gave_up": n_err, "of_those_kernel_iterate_within_1e-3_of_independent_optimum": int(n_match), "worst_rel_distance_to_independent_optimum": worst}
     print(json.dumps({"workload": "closed loop, %s N=40, %d cars x %d steps on fss2019, seed %d" % (a.model, a.cars, a.steps, a.seed),
                       "exitflag_tally_driving_cars": tally, "independent_check_of_failing_QPs": res}))
 
