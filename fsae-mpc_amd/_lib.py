@@ -52,6 +52,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FsaempcError("libfsaempc.so not built (%s): run `make` or __graft_entry__.build(); "
                                "there is no CPU fallback" % LIB_PATH)
+        try:                       # the library and torch must share ONE HIP runtime: torch ships its own libamdhip64, and a process
+            import torch  # noqa: F401  that binds /opt/rocm's copy first and torch's afterwards ends up with a runtime that sees no device
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.fsaempc_last_error.restype = C.c_char_p
         L.fsaempc_qp_workspace_bytes.restype = C.c_longlong

@@ -757,7 +757,10 @@ DEVINL int diag_factor(const Ctx& k, v4d& Ud, v4d& Yk, v4d& rk, double floor_abs
     const double w10 = -r01 * i0 * i1;
     const double w20 = -fma(r12, w10, r02 * i0) * i2, w21 = -r12 * i1 * i2;
     const double w30 = -fma(r23, w20, fma(r13, w10, r03 * i0)) * i3, w31 = -fma(r23, w21, r13 * i1) * i3, w32 = -r23 * i2 * i3;
-    // A operand: lane (i = c, kq = q) holds W[c-4p][q] on the panel's rows, 0 elsewhere
+    // A operand: lane (i = c, kq = q) holds W[c-4p][q] on the panel's rows, 0 elsewhere.  (The compiler turns these selects into
+    // ~12 divergent regions per panel and sinks the products above into them.  A branch-free construction -- 0/1 masks times the
+    // ten values -- was measured in round 2: 34 % fewer instructions in the factorisation, but 464 instead of 79 spilled
+    // registers in the kernel and 17 % slower overall; a leaner rsqrt alone was 2 % slower for the same reason.)
     const int a_ = k.c - 4 * p;
     double wa = 0.0;
     if (k.q == 0) wa = a_ == 0 ? i0 : (a_ == 1 ? w10 : (a_ == 2 ? w20 : (a_ == 3 ? w30 : 0.0)));
@@ -1213,6 +1216,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #else
     int fbad = reg_factor_only<T>(k, acc, YL, 1e-30 * dmax);
     WAVE_SYNC();
+    STAMP(5);
 #endif
     if (NB > 0) {   // bordered factor: u_e = U^-T m_e; S = M_bb - u'u is factorised as scalars
 #ifdef QP_MFMA_SOLVES

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle shares of qp_solve_kernel from the diagnostic build (make stamps; FSAEMPC_LIB points at it).
+"""Per-phase cycle shares of qp_solve_kernel from the diagnostic build (bash tools/build_exp.sh 5 -DQP_STAMPS=1; FSAEMPC_QP_V1=1 selects the phase names of the one-wavefront kernel).
 Never quote this build's run time: read the SHARES."""
 import ctypes as C
 import os
@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-os.environ.setdefault("FSAEMPC_LIB", os.path.join(ROOT, "fsae-mpc_amd", "lib", "libfsaempc_stamps.so"))
+os.environ.setdefault("FSAEMPC_LIB", os.path.join(ROOT, "fsae-mpc_amd", "lib", "libfsaempc_exp.so"))   # bash tools/build_exp.sh 5 -DQP_STAMPS=1
 import torch  # noqa: E402
 import fsae_mpc_amd as fm  # noqa: E402
 
