@@ -849,8 +849,12 @@ template <int T> DEVINL void reg_backward(const Ctx& k, const v4d* acc, const do
 // Vector layouts: "by column": lane (c, .) holds v[c];  "by row": reg p of lane (., q) holds v[q + 4p]  (each replicated
 // over the other lane coordinate).  Tiles are in accumulator layout: lane (c,q), reg p <-> X[q+4p][c].
 // ---------------------------------------------------------------------------------------------
+// REFINE: the diagonal blocks are applied through their explicit inverses U_KK^-T (LDS tiles); one step of refinement against
+// U_KK itself makes that as accurate as a substitution.  The two step directions of an iteration need it (with right-hand sides
+// riding along the factorisation, as in round 1, they went through substitution-like panel operations; without it 1 of 4096
+// kinematic N = 20 instances diverged), the corrector solve never had it.
 // U'y = b:  t_K = b_K - sum_{I<K} U_IK' y_I (by column),  y_K = U_KK^-T t_K (by row).  B: LDS vector (core part).
-template <int T> DEVINL void vec_forward(const Ctx& k, const v4d* acc, const double* YL, const double* B, double (&y)[T][4]) {
+template <int T, bool REFINE> DEVINL void vec_forward(const Ctx& k, const v4d* acc, const double* YL, const double* B, double (&y)[T][4]) {
 #pragma unroll
   for (int K = 0; K < T; ++K) {
     double s = 0.0;
@@ -862,24 +866,40 @@ template <int T> DEVINL void vec_forward(const Ctx& k, const v4d* acc, const dou
     const v4d Yt = tile_load(k, YL + K * 272);                                        // U_KK^-T
 #pragma unroll
     for (int p = 0; p < 4; ++p) y[K][p] = grp16_sum(Yt[p] * t);                       // y_K[q+4p] = sum_c Y[q+4p][c] t[c]
+    if (REFINE) {
+      const v4d& U = acc[Tri<T>::idx(K, K)];
+      double r = 0.0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) r = fma(U[p], y[K][p], r);
+      r = t - q_sum(r);                                                               // t - U_KK' y  (by column)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) y[K][p] += grp16_sum(Yt[p] * r);
+    }
   }
 }
 // U x = y:  w_K = y_K - sum_{J>K} U_KJ x_J (by row),  x_K = U_KK^-1 w_K = (U_KK^-T)' w_K (by column) -> X (LDS vector, core part)
-template <int T> DEVINL void vec_backward(const Ctx& k, const v4d* acc, const double* YL, const double (&y)[T][4], double* X) {
+template <int T, bool REFINE> DEVINL void vec_backward(const Ctx& k, const v4d* acc, const double* YL, const double (&y)[T][4], double* X) {
   double x[T];
 #pragma unroll
   for (int K = T - 1; K >= 0; --K) {
     const v4d Yt = tile_load(k, YL + K * 272);
-    double s2 = 0.0;
+    double w[4], s2 = 0.0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       double s = 0.0;
 #pragma unroll
       for (int J = K + 1; J < T; ++J) s = fma(acc[Tri<T>::idx(K, J)][p], x[J], s);    // this lane's column of (U_KJ x_J)[q+4p]
-      const double w = y[K][p] - (K < T - 1 ? grp16_sum(s) : 0.0);
-      s2 = fma(Yt[p], w, s2);
+      w[p] = y[K][p] - (K < T - 1 ? grp16_sum(s) : 0.0);
+      s2 = fma(Yt[p], w[p], s2);
     }
     x[K] = q_sum(s2);
+    if (REFINE) {
+      const v4d& U = acc[Tri<T>::idx(K, K)];
+      double d = 0.0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) d = fma(Yt[p], w[p] - grp16_sum(U[p] * x[K]), d);  // Y' (w - U_KK x)
+      x[K] += q_sum(d);
+    }
     if (k.q == 0) X[16 * K + k.c] = x[K];
   }
 }
@@ -1227,7 +1247,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #pragma unroll
       for (int e = 0; e < NB; ++e) {
         double ue[T][4];
-        vec_forward<T>(k, acc, YL, MB + e * k.np, ue);
+        vec_forward<T, true>(k, acc, YL, MB + e * k.np, ue);
         WAVE_SYNC();
         vec_rows_store<T>(k, ue, MB + e * k.np);
       }
@@ -1270,8 +1290,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #else
     {
       double y1[T][4], y2[T][4];
-      vec_forward<T>(k, acc, YL, R1, y1);
-      vec_forward<T>(k, acc, YL, R2, y2);
+      vec_forward<T, true>(k, acc, YL, R1, y1);
+      vec_forward<T, true>(k, acc, YL, R2, y2);
       if (NB > 0) {
         WAVE_SYNC();
         vec_rows_store<T>(k, y1, R1); vec_rows_store<T>(k, y2, R2);
@@ -1280,8 +1300,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         vec_rows_load<T>(k, R1, y1); vec_rows_load<T>(k, R2, y2);
       }
       WAVE_SYNC();
-      vec_backward<T>(k, acc, YL, y1, R1);
-      vec_backward<T>(k, acc, YL, y2, R2);
+      vec_backward<T, true>(k, acc, YL, y1, R1);
+      vec_backward<T, true>(k, acc, YL, y2, R2);
     }
 #endif
     WAVE_SYNC();
@@ -1289,8 +1309,21 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   };
   // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place), on the VALU
   auto solve1 = [&](double* V) __attribute__((always_inline)) {
+#ifdef QP_MFMA_SOLVES
+    const double* vin[1] = {V}; double* vout[1] = {V};
+    rhs_load<T, 1>(k, rh, vin);
+    reg_forward<T>(k, acc, YL, rh);
+    if (NB > 0) {
+      rhs_store<T, 1>(k, rh, vout);
+      WAVE_SYNC();
+      border_solve(V);
+      rhs_load<T, 1>(k, rh, vin);
+    }
+    reg_backward<T>(k, acc, YL, rh, SCR);
+    rhs_store<T, 1>(k, rh, vout);
+#else
     double yv[T][4];
-    vec_forward<T>(k, acc, YL, V, yv);
+    vec_forward<T, false>(k, acc, YL, V, yv);
     if (NB > 0) {
       WAVE_SYNC();
       vec_rows_store<T>(k, yv, V);
@@ -1299,7 +1332,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       vec_rows_load<T>(k, V, yv);
     }
     WAVE_SYNC();
-    vec_backward<T>(k, acc, YL, yv, V);
+    vec_backward<T, false>(k, acc, YL, yv, V);
+#endif
   };
 
   STAMP(0);

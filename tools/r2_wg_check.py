@@ -19,14 +19,14 @@ def shape(model, N, B, polish=0, timing=True):
     out = fm.qp_solve_batch_device(*args, options=o, want_lambda=True)
     torch.cuda.synchronize()
     x = out["x"].cpu().numpy(); fl = out["exitflag"].cpu().numpy(); it = out["iter"].cpu().numpy(); lam = out["lam"].cpu().numpy()
-    nchk = min(B, 64)
+    nchk = min(B, int(os.environ.get('NCHK', '64')))
     xo, fo, flo, ito, lamo, _ = orc.qp_solve_batch(*[q[k][:nchk] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")], orc.default_opts(polish=polish))
     ok = (fl[:nchk] == 0) & (flo == 0)
     ex = np.abs(x[:nchk] - xo).max(axis=1) / np.maximum(1, np.abs(xo).max(axis=1))
     kk = np.array([orc.qp_kkt(q["H"][b].T, q["g"][b], q["A"][b].T, q["lb"][b], q["ub"][b], q["lbA"][b], q["ubA"][b], x[b], lam[b])[0] if fl[b] == 0 else np.nan for b in range(nchk)])
-    msg = "model %d N %2d B %4d: flags %s | iters mean %.2f (oracle %.2f, same %d/%d) | x err vs oracle max %.1e med %.1e | kkt max %.1e" % (
+    msg = "model %d N %2d B %4d: flags %s | iters mean %.2f (oracle %.2f, same %d/%d) | x err vs oracle max %.1e med %.1e p90 %.1e | kkt max %.1e" % (
         model, N, B, dict(zip(*np.unique(fl, return_counts=True))), it.mean(), ito.mean(), int((it[:nchk] == ito).sum()), nchk,
-        np.nanmax(np.where(ok, ex, np.nan)) if ok.any() else np.nan, np.nanmedian(np.where(ok, ex, np.nan)) if ok.any() else np.nan, np.nanmax(kk) if np.isfinite(kk).any() else np.nan)
+        np.nanmax(np.where(ok, ex, np.nan)) if ok.any() else np.nan, np.nanmedian(np.where(ok, ex, np.nan)) if ok.any() else np.nan, np.nanpercentile(np.where(ok, ex, np.nan), 90) if ok.any() else np.nan, np.nanmax(kk) if np.isfinite(kk).any() else np.nan)
     if timing:
         ws = out["workspace"]
         torch.cuda.synchronize(); t0 = time.perf_counter()
