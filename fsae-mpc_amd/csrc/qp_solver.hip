@@ -378,8 +378,9 @@ template <int C> struct IC { static constexpr int value = C; };
 //   (The wrong iterates of some -O2/-O3 builds were NOT a ring hazard: DESIGN.md, "Build-variant fragility: root cause".)
 // The asm memory clobbers keep the compiler from moving LDS reads or DMA issues across the wait.
 // ---------------------------------------------------------------------------------------------
+#ifdef QP_DRAIN_STREAM   // the full-drain double buffer of the fragility investigation (kept for A/B runs): lead = one pair
 template <int T> struct StreamCfg {
-  static constexpr int R = 2 * T;   // ring capacity: two pairs of k-steps
+  static constexpr int R = 3 * T;   // (ring sized as below so that both variants share the LDS layout)
 };
 template <int T> struct Stream {
   static constexpr int R = StreamCfg<T>::R;
@@ -392,12 +393,9 @@ template <int T> struct Stream {
   }
   DEVINL void start(const Ctx& k, int c0) {   // c0: tile count of the first pair
     gnext = reinterpret_cast<const char*>(k.Aw); half = 0;
-
 #pragma unroll
     for (int t = 0; t < T; ++t) if (t < c0) issue(k, t);
   }
-  // waits for the C records of the current pair, issues the cn records of the pair after it (0 at the end of the stream)
-  // into the other half and reads the current pair
   template <int C> DEVINL void next_pair(const Ctx& k, v2d* b, int cn) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int other = (half ^ 1) * T;
@@ -410,6 +408,45 @@ template <int T> struct Stream {
   }
   DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
+#else
+// Lead of D = 2T records (two pairs of k-steps at the full tile count, more in the sparse early trips) behind a COUNTED wait:
+// a pair's C records are consumed after C new ones have been issued and `s_waitcnt vmcnt(D)` says that at most D vector-memory
+// operations are still outstanding.  Loads (LDS-DMA, global, scratch) return in issue order, so the D newest outstanding loads
+// are never this pair's; stores may retire in any order, which can only make the wait longer, never shorter.  The producer walks
+// the linear record stream and runs up to D records past its end (still inside this QP's workspace).  One pair of lead (the
+// full-drain variant above) left passes 2 and 3 waiting on the DMA: their VALU work per pair is shorter than the latency.
+template <int T> struct StreamCfg {
+  static constexpr int D = 2 * T;
+  static constexpr int R = D + T;
+};
+template <int T> struct Stream {
+  static constexpr int D = StreamCfg<T>::D, R = StreamCfg<T>::R;
+  const char* gnext; int slot_i, slot_e;
+  DEVINL void issue(const Ctx& k) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gnext + k.lane * 16),
+                                     (__attribute__((address_space(3))) void*)(k.ring + slot_i * 128), 16, 0, 0);
+    gnext += 1024;
+    slot_i = slot_i + 1 == R ? 0 : slot_i + 1;
+  }
+  DEVINL void start(const Ctx& k, int) {
+    gnext = reinterpret_cast<const char*>(k.Aw); slot_i = 0; slot_e = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(k);
+  }
+  template <int C> DEVINL void next_pair(const Ctx& k, v2d* b, int) {
+#pragma unroll
+    for (int t = 0; t < C; ++t) issue(k);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(D) : "memory");
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+      int sl = slot_e + t; if (sl >= R) sl -= R;
+      b[t] = *reinterpret_cast<const v2d*>(k.ring + sl * 128 + k.lane * 2);
+    }
+    slot_e += C; if (slot_e >= R) slot_e -= R;
+  }
+  DEVINL void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+};
+#endif
 
 // Per-row coefficients of a pass (owner layout [slot][64] in global memory): one slot (16 k-steps) at a time is staged
 // in LDS -- NA wave-wide loads per 16 k-steps instead of NA broadcast loads per k-step -- and read back as 16-byte
@@ -972,11 +1009,11 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   k.aoff = k.tcs + d.ntr; k.tend = k.aoff + d.ntr + 1;
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
-  double* MB = lds + (size_t)V_NARR * d.np;    // 4 border-column vectors (A'DA border, then U^-T m_b)
-  double* SCR = MB + (size_t)4 * d.np;          // 16 x 17 tile-transpose scratch
-  double* YL = SCR + 16 * 17 + 16;              // T resident tiles U_KK^-T
+  double* MB = lds + (size_t)V_NARR * d.np;    // NB border-column vectors (A'DA border, then U^-T m_b)
+  double* YL = MB + (size_t)(NB > 0 ? NB : 1) * d.np;   // T resident tiles U_KK^-T (MB: one vector per border column)
   k.ring = YL + T * 272;                        // operand ring of the streaming passes
   k.cof = k.ring + StreamCfg<T>::R * 128;       // coefficient staging, (6 + NB) arrays of 64
+  double* SCR = k.ring;                         // 16 x 17 tile-transpose scratch of the MFMA solves (A/B builds): the ring is idle then
   const double* gw = ws + d.off_gw;
   const double* Es = ws + d.off_E;
   const double* Fs = ws + d.off_F;
@@ -1999,7 +2036,7 @@ template <int T, int NB> __global__ __launch_bounds__(64) void syrk_probe_kernel
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
   double* MB = lds + (size_t)V_NARR * d.np;
-  k.ring = MB + (size_t)4 * d.np + 16 * 17 + 16 + T * 272; k.cof = k.ring + StreamCfg<T>::R * 128;
+  k.ring = MB + (size_t)(NB > 0 ? NB : 1) * d.np + T * 272; k.cof = k.ring + StreamCfg<T>::R * 128;
   for (int js = 0; js < k.JT; ++js) {
     const int ix = js * 64 + k.lane;
     rowp(k, R_D)[ix] = 1.0; rowp(k, R_W1)[ix] = 0.5; rowp(k, R_W2)[ix] = 0.25; rowp(k, R_W3)[ix] = 2.0;
@@ -2036,9 +2073,9 @@ template <int T> __global__ __launch_bounds__(64) void factor_probe_kernel(QpPar
   extern __shared__ double lds[];
   k.Ms = nullptr; k.vec = lds;
   double* MB = lds + (size_t)V_NARR * d.np;
-  double* SCR = MB + (size_t)4 * d.np;
-  double* YL = SCR + 16 * 17 + 16;
+  double* YL = MB + (size_t)1 * d.np;
   k.ring = YL + T * 272; k.cof = k.ring + StreamCfg<T>::R * 128;
+  double* SCR = k.ring;
   v4d acc[Tri<T>::NT], rh[T];
   unsigned long long tt[4] = {0, 0, 0, 0};
   double cs = 0;
@@ -2114,7 +2151,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
   {
-    d->lds_solve = ((size_t)(V_NARR + 4) * d->np + 16 * 17 + 16 + (size_t)d->T * 272 + (size_t)(2 * d->T + 2) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);   // ring = StreamCfg<T>::R records (+2 spare)
+    d->lds_solve = ((size_t)(V_NARR + (d->NB ? d->NB : 1)) * d->np + (size_t)d->T * 272 + (size_t)(3 * d->T) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);   // ring = StreamCfg<T>::R = 3T records
   }
   {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP.  The operand stream of A~ stays resident in LDS when
       // ~2/3 of its dense size fits (structurally empty tiles are skipped, the LTV-MPC families keep ~60 %) and the rows

@@ -5,7 +5,7 @@ S="${AB_SHAPES:-0,40,4096,1;1,40,2048,1;0,39,1024,1;0,20,4096,1}"
 for rep in 1 2; do
 for lib in $AB_LIBS; do
   n=$(basename $lib .so)
-  FSAEMPC_LIB=$PWD/$lib SHAPES="$S" timeout -k 10 300 python tools/r2_wg_check.py > $out/$n.$rep.log 2>&1 || echo "$n rc=$?"
+  FSAEMPC_LIB=$PWD/$lib SHAPES="$S" timeout -k 10 300 python tools/check_vs_oracle.py > $out/$n.$rep.log 2>&1 || echo "$n rc=$?"
   echo "== $n (run $rep)"; grep "^model" $out/$n.$rep.log | cut -c1-40,95-260
 done
 done

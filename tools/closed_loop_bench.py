@@ -29,6 +29,9 @@ def main():
     n_act = int(ac.sum())
     hist = {int(k_): int(c_) for k_, c_ in zip(*np.unique(fl[ac], return_counts=True))}
     solved = int(((fl == 0) & ac).sum())
+    bad_data = int(((fl == -1) & (it == 0) & ac).sum())    # -1 before the first iteration = non-finite QP data (vehicle state outside
+                                                           # the model's domain, e.g. v_x -> 0 in the dynamic model): the reference's
+                                                           # MEX gateway rejects such a call ("Argument contains NaN")
     x0 = cl.x0.cpu().numpy()
     print(json.dumps({
         "metric": "QP solves/sec (closed loop, %s N=%d, fp64)" % (a.model, a.horizon), "value": solved / dt_wall, "unit": "QP solves/s",
@@ -37,7 +40,8 @@ def main():
                                "(frame transform + reference + linearise/condense/solve + PID/plant, device-resident loop, no per-step read-back; "
                                "wall time includes the allocation of the run)" % (a.batch, a.steps),
                    "qps_of_driving_cars": n_act, "qps_total_launched": int(a.batch * a.steps),
-                   "exitflag_histogram_driving_cars": hist, "abnormal_exit_pct": 100.0 * (1.0 - solved / max(1, n_act)),
+                   "exitflag_histogram_driving_cars": hist, "minus1_with_nonfinite_qp_data": bad_data,
+                   "minus1_on_finite_qp_data_pct": 100.0 * (hist.get(-1, 0) - bad_data) / max(1, n_act), "abnormal_exit_pct": 100.0 * (1.0 - solved / max(1, n_act)),
                    "mean_ipm_iterations": float(it[ac].mean()) if n_act else 0.0,
                    "cars_past_end_of_track_parameter": int((cl.finished == 1).sum().item()), "cars_lost": int((cl.finished == 2).sum().item()),
                    "mean_speed_end": float(cl.cart[:, 3].mean().item()),
