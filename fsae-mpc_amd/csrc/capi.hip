@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "fsaempc.h"
@@ -15,8 +16,11 @@
 
 namespace {
 thread_local char g_err[512] = "";
-double* g_dump = nullptr; int g_dump_stage = 0, g_dump_iter = 0;   // diagnostic builds only
-bool g_timing = false; hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+// Diagnostics (fsaempc_debug_set_dump, fsaempc_qp_set_timing): process-wide switches meant for ONE measuring thread (bench.py,
+// tools/).  Atomics keep a solve on another thread well-defined while they are flipped; the event triple itself is not
+// per-thread, so timing figures are only meaningful when a single thread launches solves.
+std::atomic<double*> g_dump{nullptr}; std::atomic<int> g_dump_stage{0};
+std::atomic<bool> g_timing{false}; hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 
 int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); return code; }
 int hipfail(hipError_t e, const char* where) {
@@ -69,12 +73,13 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double*
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
   P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr;
   P.shared_HA = desc->shared_HA;
-  P.dump = g_dump; P.dump_stage = g_dump_stage & 0xff; P.dump_iter = g_dump_stage >> 8;
+  { const int st = g_dump_stage.load(); P.dump = g_dump.load(); P.dump_stage = st & 0xff; P.dump_iter = st >> 8; }
+  const bool timing = g_timing.load();
   hipError_t e;
-  if (g_timing) { e = hipEventRecord(g_ev[0], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
-  e = qp_launch(P, desc->batch, (hipStream_t)stream, g_timing ? g_ev[1] : nullptr);
+  if (timing) { e = hipEventRecord(g_ev[0], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
+  e = qp_launch(P, desc->batch, (hipStream_t)stream, timing ? g_ev[1] : nullptr);
   if (e != hipSuccess) return hipfail(e, "qp_launch");
-  if (g_timing) { e = hipEventRecord(g_ev[2], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
+  if (timing) { e = hipEventRecord(g_ev[2], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
   return 0;
 }
 
@@ -414,13 +419,13 @@ int fsaempc_selftest_mfma(void) {
   return bad;
 }
 
-int fsaempc_debug_set_dump(double* out, int stage) { g_dump = out; g_dump_stage = stage; return 0; }
+int fsaempc_debug_set_dump(double* out, int stage) { g_dump.store(out); g_dump_stage.store(stage); return 0; }
 
 int fsaempc_qp_set_timing(int enable) {
   if (enable && !g_ev[0]) {
     for (int i = 0; i < 3; ++i) { hipError_t e = hipEventCreate(&g_ev[i]); if (e != hipSuccess) return hipfail(e, "hipEventCreate"); }
   }
-  g_timing = enable != 0;
+  g_timing.store(enable != 0);
   return 0;
 }
 

@@ -16,7 +16,7 @@ struct QpDims {
   int J, JB;       // owner-layout slots for rows / for variable bounds
   int ld;          // leading dimension of the LDS normal matrix
   int rowlen;      // (J+JB)*64
-  size_t off_Aw, off_meta, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, ws_per_qp;  // in doubles
+  size_t off_Aw, off_meta, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, off_bad, ws_per_qp;  // in doubles (off_bad: 1.0 if the prep kernel met NaN / Inf in the QP's data)
   size_t lds_solve, lds_prep;                                                  // in bytes
   int W;                  // wavefronts per QP of the workgroup solve kernel (qp_wg.hip)
   int NBk;                // border width of the kernel variant: 0, 1 (only nb == 1 and T <= QP_WG_RES_MAX_T) or 4

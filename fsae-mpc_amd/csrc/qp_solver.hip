@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
       __syncthreads();
     }
   }
-  for (int j = tid; j < np; j += 256) { Es[j] = Esh[j]; gw[j] = j < n ? g[j] * Esh[j] : 0.0; }
+  int bad = 0;   // NaN / Inf anywhere in H, g, A or NaN in a bound: the solve kernel answers -1 before its first iteration (the
+                 // reference's MEX gateway rejects such a call; a device entry cannot look at the data before the launch)
+  for (int j = tid; j < np; j += 256) { Es[j] = Esh[j]; gw[j] = j < n ? g[j] * Esh[j] : 0.0; bad |= j < n && !(fabs(g[j]) < INFINITY); }
 
   // ---- row order: class = last core column tile with a nonzero; stable counting sort by class ----
   if (tid < 16) cnt_sh[tid] = 0;
@@ -224,10 +226,11 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     Fs[js * 64 + lane] = f;
     perm_g[js * 64 + lane] = r;
     for (int bb = 0; bb < 4; ++bb)
-      Ab[(size_t)bb * J * 64 + js * 64 + lane] = (valid && bb < nb) ? A[(size_t)(nc + bb) * m + r] * Esh[nc + bb] * f : 0.0;
+    { const double v = (valid && bb < nb) ? A[(size_t)(nc + bb) * m + r] * Esh[nc + bb] * f : 0.0; bad |= !(fabs(v) < INFINITY); Ab[(size_t)bb * J * 64 + js * 64 + lane] = v; }
     double l = -INFINITY, u = INFINITY;
     if (valid) {
       double lr = P.lbA[(size_t)b * m + r], ur = P.ubA[(size_t)b * m + r];
+      bad |= (lr != lr) || (ur != ur);
       l = lr > -P.inf_bound ? lr * f : -INFINITY;
       u = ur < P.inf_bound ? ur * f : INFINITY;
     }
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     double l = -INFINITY, u = INFINITY;
     if (i < n) {
       double lr = P.lb[(size_t)b * n + i], ur = P.ub[(size_t)b * n + i];
+      bad |= (lr != lr) || (ur != ur);
       l = lr > -P.inf_bound ? lr / Esh[i] : -INFINITY;
       u = ur < P.inf_bound ? ur / Esh[i] : INFINITY;
     }
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
         const int col = 16 * t + c0 + cc;
         double v = 0.0;
         if (col < nc && col < n && r < m) v = A[(size_t)col * m + r] * Esh[col];
+        bad |= !(fabs(v) < INFINITY);
         tile[cc * mp1 + r] = v;
       }
       __syncthreads();
@@ -276,12 +281,17 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     const int row = 16 * I + q + 4 * p, col = 16 * Jt + c;
     double v = 0.0;
     if (row < nc && col < nc && row < n && col < n) v = H[(size_t)row * n + col] * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
+    bad |= !(fabs(v) < INFINITY);
     Hw[(size_t)idx * 64 + lane] = v;
   }
   for (int e = tid; e < 4 * np; e += 256) {
     const int bb = e / np, i = e - bb * np;
-    Hb[e] = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
+    const double v = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
+    bad |= !(fabs(v) < INFINITY);
+    Hb[e] = v;
   }
+  bad = __syncthreads_or(bad);
+  if (tid == 0) ws[d.off_bad] = bad ? 1.0 : 0.0;
 }
 
 #endif  // QP_MAIN_TU
@@ -1103,6 +1113,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   int flag = 1, it = 0, flag_polished = 0;
   double fval_s = 0.0, merit_s = INFINITY;   // objective / relative KKT residual of the point that is returned
   if (infeas) { flag = -2; }
+  if (ws[d.off_bad] != 0.0) flag = -1;   // NaN / Inf in this QP's data (found by the prep kernel): -1 after 0 iterations, x = clamp(0, lb, ub)
 
   // ---- v = G x ----
   {
@@ -2148,6 +2159,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->off_Hb = off; off += (size_t)4 * d->np;
   d->off_rows = off; off += (size_t)R_NARR * d->rowlen;
   d->off_save = off; off += d->np + d->rowlen;
+  d->off_bad = off; off += 2;
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
   {

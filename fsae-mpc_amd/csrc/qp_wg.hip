@@ -330,6 +330,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   int flag = 1, it = 0, flag_polished = 0;
   double fval_s = 0.0, merit_s = INFINITY;   // objective / relative KKT residual of the point that is returned
   if (infeas) flag = -2;
+  if (ws[d.off_bad] != 0.0) flag = -1;   // NaN / Inf in this QP's data (found by the prep kernel): -1 after 0 iterations
   STAMP_DECL
 
   // ------------------------------------------------------------------------------------------

@@ -103,7 +103,9 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc,
 
 /* Same call on host pointers: copies to the device, solves, copies back, synchronises.
  * This is what a MEX gateway calls (mex/qpOASES.cpp); validates like the original gateway
- * (NaN anywhere / Inf in H,g,A => FSAEMPC_ERR_ARG). */
+ * (NaN anywhere / Inf in H,g,A => FSAEMPC_ERR_ARG).  The _device entries cannot inspect device data before the launch: an
+ * instance with NaN / Inf in H, g, A (or NaN in a bound) returns exitflag -1 with iter = 0 and x = clamp(0, lb, ub); the other
+ * instances of the batch are unaffected. */
 int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc,
                            const double* H, const double* g, const double* A,
                            const double* lb, const double* ub, const double* lbA, const double* ubA,

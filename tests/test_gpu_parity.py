@@ -323,6 +323,27 @@ def test_sequence_api(fm, orc, otrack):
         fm.qpOASES_sequence("c", QP)
 
 
+def test_nonfinite_qp_data_on_the_device_entry(fm, torch_):
+    """The host-buffer entry rejects NaN / Inf like the MEX gateway does (FSAEMPC_ERR_ARG); the device entry cannot look at the
+    data before the launch: such an instance comes back with exit flag -1 after 0 iterations and a finite x, its neighbours in
+    the batch are unaffected (the closed loop relies on this: a car whose linearisation blew up keeps its last good plan)."""
+    torch = torch_
+    rng = np.random.default_rng(11)
+    n, m, B = 20, 12, 4
+    Q = rng.normal(size=(B, n, n)); H = Q @ Q.transpose(0, 2, 1) + n * np.eye(n); g = rng.normal(size=(B, n))
+    A = rng.normal(size=(B, n, m)); lb = -np.ones((B, n)); ub = np.ones((B, n)); lbA = -np.ones((B, m)); ubA = np.ones((B, m))
+    g[1, 3] = np.nan; H[2, 4, 4] = np.inf
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    o = fm.qp_solve_batch_device(d(H), d(g), d(A), d(lb), d(ub), d(lbA), d(ubA), want_aux=True)
+    torch.cuda.synchronize()
+    fl = o["exitflag"].cpu().numpy(); it = o["iter"].cpu().numpy()
+    assert fl[0] == 0 and fl[3] == 0 and fl[1] == -1 and fl[2] == -1, fl
+    assert it[1] == 0 and it[2] == 0, it
+    assert torch.isfinite(o["x"]).all()
+    with pytest.raises(fm.FsaempcError, match="NaN"):
+        fm.qpOASES(H[1], g[1], A[1].T, lb[1], ub[1], lbA[1], ubA[1])
+
+
 def test_sequence_equality_call(fm):
     """qpOASES_sequence('e') (qpOASES_sequence.m:64): the equality-constrained QP fixed by the working set of the last solve,
     checked against a dense KKT solve with numpy (independent of the solver)."""
