@@ -1003,6 +1003,9 @@ template <int T, int NS> DEVINL void rhs_store(const Ctx& k, const v4d* rh, doub
 #define STAMP_OUT do { } while (0)
 #endif
 
+#ifndef QP_REFINE_ATTEMPTS
+#define QP_REFINE_ATTEMPTS 3
+#endif
 #ifndef QP_WAVES_PER_SIMD
 #define QP_WAVES_PER_SIMD 1
 #endif
@@ -1728,9 +1731,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }
     for (int i = lane; i < k.np; i += 64) XS[i] = X[i];   // z of the refinement between attempts (the fall-back copy is no longer needed)
     WAVE_SYNC();
-    // up to three attempts: a refinement that ends on a violated inactive row / a multiplier of the wrong sign adds / drops
+    // up to QP_REFINE_ATTEMPTS attempts: a refinement that ends on a violated inactive row / a multiplier of the wrong sign adds / drops
     // that one row and starts over from the point it reached (single add-drop corrections of an active-set method)
-    for (int attempt = 0; attempt < 3 && flag_polished <= 0; ++attempt) {
+    for (int attempt = 0; attempt < QP_REFINE_ATTEMPTS && flag_polished <= 0; ++attempt) {
     for (int js = 0; js < JT; ++js) {
       const int ix = js * 64 + lane;
       const double sd = PS[ix];
@@ -1811,7 +1814,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         const double pq = wave_sum(pq_l);
         if (!(pq > 0.0) || !(rs > 0.0)) {   // dependent / inconsistent working set: drop the row that carries the stalled direction
           pok = false; flag_polished = -7;
-          if (attempt < 2) {
+          if (attempt < QP_REFINE_ATTEMPTS - 1) {
             double my = 0.0; int myix = -1;
             for (int js = 0; js < J; ++js) { const int ix = js * 64 + lane; if (PA[ix] != 0.0 && fabs(PP[ix]) > my) { my = fabs(PP[ix]); myix = ix; } }
             const double mx = wave_max(my);
@@ -1896,7 +1899,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       // (round-off level wrong signs are zeroed)
       pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8;
       if (!pok) flag_polished = !(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3));
-      if (!pok && m_rd <= 1e-8 && attempt < 2 && (m_rp > 1e-10 || m_sg > 1e-8)) {
+      if (!pok && m_rd <= 1e-8 && attempt < QP_REFINE_ATTEMPTS - 1 && (m_rp > 1e-10 || m_sg > 1e-8)) {
         // single correction of the working set: add the most violated inactive row, else drop the worst wrong-sign row
         double my = 0.0; int myix = -1; double myside = 0.0;
         const bool add = m_rp > 1e-10;
@@ -1927,7 +1930,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
         WAVE_SYNC();
         continue;   // next attempt from the point reached (R2) with the corrected working set
       }
-      if (!pok && !(m_rd <= 1e-8) && attempt < 2 && m_rd <= 1e-4) {   // stationarity above the floor: one more exact step from here
+      if (!pok && !(m_rd <= 1e-8) && attempt < QP_REFINE_ATTEMPTS - 1 && m_rd <= 1e-4) {   // stationarity above the floor: one more exact step from here
         for (int i = lane; i < k.np; i += 64) XS[i] = R2[i];
         for (int js = 0; js < J; ++js) { const int ix = js * 64 + lane; PY[ix] = PS[ix] != 0.0 ? aVC[ix] : 0.0; }
         WAVE_SYNC();
