@@ -371,6 +371,39 @@ template <int T> DEVINL void acc_init(const Ctx& k, v4d* acc) {
     }
 }
 
+// H~x of the core from the freshly initialised accumulators (the upper tiles of H~ that pass 1 is about to add A'DA to), so the
+// 51 KB of H~ are read once per iteration instead of twice.  Tile (I,J), I <= J, in accumulator layout gives (H_IJ' x_I)[c] for
+// block J with four FMAs and, for I < J, (H_IJ x_J)[q+4p] for block I with four more; the lane-group / DPP-row sums are taken
+// once per block, not per tile.  XV, HX: LDS vectors.
+template <int T> DEVINL void hx_from_acc(const Ctx& k, const v4d* acc, const double* XV, double* HX) {
+  double xr[T][4], xc[T], sc[T], sr[T][4];
+#pragma unroll
+  for (int I = 0; I < T; ++I) {
+    xc[I] = XV[16 * I + k.c]; sc[I] = 0.0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { xr[I][p] = XV[16 * I + k.q + 4 * p]; sr[I][p] = 0.0; }
+  }
+#pragma unroll
+  for (int I = 0; I < T; ++I)
+#pragma unroll
+    for (int J = I; J < T; ++J) {
+      const v4d& h = acc[Tri<T>::idx(I, J)];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        sc[J] = fma(h[p], xr[I][p], sc[J]);                 // column form: this lane group's rows of (H_IJ' x_I)[c]
+        if (J > I) sr[I][p] = fma(h[p], xc[J], sr[I][p]);   // row form: this lane's column of (H_IJ x_J)[q+4p]
+      }
+    }
+  WAVE_SYNC();
+#pragma unroll
+  for (int J = 0; J < T; ++J) { const double v = q_sum(sc[J]); if (k.q == 0) HX[16 * J + k.c] = v; }
+  WAVE_SYNC();
+#pragma unroll
+  for (int I = 0; I < T - 1; ++I)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { const double v = grp16_sum(sr[I][p]); if (k.c == 0) HX[16 * I + k.q + 4 * p] += v; }
+}
+
 template <int C> struct IC { static constexpr int value = C; };
 
 // ---------------------------------------------------------------------------------------------
@@ -1061,8 +1094,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 #define aRPU rowp(k, R_RPU)
 
   // Hx = H~ x: core through the tile grid, border columns (full-length vectors Hb[b]) on the VALU
-  auto hx_full = [&](const double* XV) __attribute__((always_inline)) {
-    hx_tiles<T>(k, XV, HX);
+  auto hx_border = [&](const double* XV) __attribute__((always_inline)) {
     if (NB > 0) {
       WAVE_SYNC();
       double xb[NBB], sb[NBB];
@@ -1081,6 +1113,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       for (int e = 0; e < NB; ++e) { const double tot = wave_sum(sb[e]); if (lane == 0) HX[nc + e] = tot; }
     }
   };
+  auto hx_full = [&](const double* XV) __attribute__((always_inline)) { hx_tiles<T>(k, XV, HX); hx_border(XV); };
 
   // ---- load n-vectors, initial x = clamp(0, l, u) (scaled), count finite sides ----
   for (int i = lane; i < k.np; i += 64) { G[i] = gw[i]; EV[i] = Es[i]; R1[i] = 0; R2[i] = 0; DX[i] = 0; }
@@ -1404,9 +1437,16 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
 
     STAMP(1);
     // ================= pass 1: M = H + A'DA (MFMA), p1, p2, p3; Hx =================
+#ifdef QP_HX_SEPARATE   // round-1 form (A/B runs): H~ read once for H~x and once more for the accumulators
     hx_full(X);
     STAMP(2);
     acc_init<T>(k, acc);
+#else
+    acc_init<T>(k, acc);
+    hx_from_acc<T>(k, acc, X, HX);
+    hx_border(X);
+    STAMP(2);
+#endif
     pass_syrk<T, NB>(k, acc, P1, P2, P3, MB);
     WAVE_SYNC();
     STAMP(3);
