@@ -34,6 +34,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define DEVINL __device__ __forceinline__
+#ifndef QP_SOLVE_REFINE_STEPS
+#define QP_SOLVE_REFINE_STEPS 1   // refinement steps of the diagonal-block solves in vec_forward / vec_backward
+#endif
 // The solve kernel runs one wavefront per workgroup: its lanes exchange data through LDS (and their own rows of global
 // memory) in program order, and the hardware keeps the DS / vector-memory operations of one wave in order, so a
 // workgroup barrier (s_barrier + full s_waitcnt drain) is not needed -- a compiler-level fence is.
@@ -948,12 +951,15 @@ template <int T, bool REFINE> DEVINL void vec_forward(const Ctx& k, const v4d* a
     for (int p = 0; p < 4; ++p) y[K][p] = grp16_sum(Yt[p] * t);                       // y_K[q+4p] = sum_c Y[q+4p][c] t[c]
     if (REFINE) {
       const v4d& U = acc[Tri<T>::idx(K, K)];
-      double r = 0.0;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) r = fma(U[p], y[K][p], r);
-      r = t - q_sum(r);                                                               // t - U_KK' y  (by column)
+      for (int rep = 0; rep < QP_SOLVE_REFINE_STEPS; ++rep) {
+        double r = 0.0;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) y[K][p] += grp16_sum(Yt[p] * r);
+        for (int p = 0; p < 4; ++p) r = fma(U[p], y[K][p], r);
+        r = t - q_sum(r);                                                             // t - U_KK' y  (by column)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) y[K][p] += grp16_sum(Yt[p] * r);
+      }
     }
   }
 }
@@ -975,10 +981,13 @@ template <int T, bool REFINE> DEVINL void vec_backward(const Ctx& k, const v4d* 
     x[K] = q_sum(s2);
     if (REFINE) {
       const v4d& U = acc[Tri<T>::idx(K, K)];
-      double d = 0.0;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) d = fma(Yt[p], w[p] - grp16_sum(U[p] * x[K]), d);  // Y' (w - U_KK x)
-      x[K] += q_sum(d);
+      for (int rep = 0; rep < QP_SOLVE_REFINE_STEPS; ++rep) {
+        double d = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) d = fma(Yt[p], w[p] - grp16_sum(U[p] * x[K]), d);  // Y' (w - U_KK x)
+        x[K] += q_sum(d);
+      }
     }
     if (k.q == 0) X[16 * K + k.c] = x[K];
   }
@@ -1516,9 +1525,10 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     STAMP(4);
     if (factor_solve2(it)) {
       flag = (res_ok || have_saved) ? 2 : -1;
-      // the factorisation broke down (weights ~1e24) on an iterate that is primal feasible and complementary to tol_loose;
-      // only the dual residual is numerical noise: let the polish certify it (flag 4 -> 0 if accepted, else -1)
-      if (flag == -1 && P.polish && rp_rel <= P.tol_loose && gap_rel <= P.tol_loose) flag = 4;
+      // the factorisation broke down (weights ~1e24) on an iterate that is nearly primal feasible and complementary: its working
+      // set is usually the right one already, so the refinement gets a try -- it accepts nothing that is not a KKT point of the
+      // full QP by a fresh evaluation (flag 4 -> 0 if accepted, else -1)
+      if (flag == -1 && P.polish && rp_rel <= 1e-4 && gap_rel <= 1e-4) flag = 4;
       break;
     }
     STAMP(6);
@@ -1720,7 +1730,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     if (zn > 1e15 && rp_prev > 1e-6) { flag = -2; break; }
     // once an iterate met tol_loose, a handful of non-improving iterations means the end game lost its numerical
     // footing: return the saved iterate (this also bounds the iteration tail, i.e. the kernel's drain time)
-    if (stall > (have_saved ? 5 : 25)) { flag = have_saved ? 2 : (rp_prev > 1e-6 ? -2 : 1); break; }
+    if (stall > (have_saved ? 5 : 25)) { flag = have_saved ? 2 : (rp_prev > 1e-6 ? -2 : (P.polish ? 5 : 1)); break; }   // 5: stalled, the refinement may still certify (else 1)
   }
 
   // ---- outputs ----
@@ -1751,7 +1761,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   // could not (rejected 10-20 % of the instances).  One fused stream over A~ per CG step (q = A_W w and A_W'q together),
   // A'p kept by recurrence.  The result is accepted only if a fresh evaluation says it is a KKT point of the full QP;
   // otherwise the interior-point iterate is returned.
-  if ((flag == 0 || flag == 4) && P.polish) {
+  if ((flag == 0 || flag == 4 || flag == 5) && P.polish) {
     const double rho = 1e6, pin = 1e16, rinv = 1.0 / rho;
     double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
     double* PC = rowp(k, R_RPU); double* PP = rowp(k, R_CC2); double* PZ0 = aW2;   // constraint residual c, CG direction p, zeros
@@ -1993,6 +2003,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     }   // attempts
   }
   if (flag == 4) flag = -1;   // not certified
+  if (flag == 5) flag = 1;
   double* xo = P.x + (size_t)b * n;
   for (int i = lane; i < n; i += 64) xo[i] = X[i] * EV[i];
   if (P.lambda) {

@@ -495,7 +495,7 @@ int orc_qp_solve_ex(int nV, int nC, const double* H, const double* g, const doub
     { int ce = chol_lower(n, M, 1e-30 * dmax); if (ce) { if (opts.verbose) printf("chol fail at %d dmax %g\n", ce, dmax); flag = res_ok ? 0 : (have_saved ? 2 : -1);
         /* the factorisation broke down (weights ~1e24) on an iterate that is primal feasible and complementary to
          * tol_loose; only the dual residual is numerical noise: let the active-set polish certify it (flag 4) */
-        if (flag == -1 && opts.polish && rp_rel <= opts.tol_loose && gap_rel <= opts.tol_loose) flag = 4;
+        if (flag == -1 && opts.polish && rp_rel <= 1e-4 && gap_rel <= 1e-4) flag = 4;   /* nearly feasible and complementary: the refinement gets a try */
         break; } }
 
     /* predictor */
@@ -598,11 +598,11 @@ int orc_qp_solve_ex(int nV, int nC, const double* H, const double* g, const doub
     if (zn > 1e15 && rp_rel > 1e-6) { flag = -2; break; }
     /* once an iterate met tol_loose, a handful of non-improving iterations means the end game has lost its
      * numerical footing: stop early and return the saved iterate (bounds the iteration tail of a batch) */
-    if (stall > (have_saved ? 5 : 25)) { flag = rp_rel > 1e-6 && !have_saved ? -2 : 1; break; }
+    if (stall > (have_saved ? 5 : 25)) { flag = rp_rel > 1e-6 && !have_saved ? -2 : ((opts.polish && !have_saved) ? 5 : 1); break; }   /* 5: stalled, refinement may certify */
   }
 
 finish:
-  if (flag == 2 || ((flag == 1 || flag == -1) && have_saved)) {
+  if (flag == 2 || ((flag == 1 || flag == -1 || flag == 5) && have_saved)) {
     /* fall back to the last iterate that met the residual tolerances */
     for (int j = 0; j < n; ++j) x[j] = xs[j];
     for (int i = 0; i < mt; ++i) { zl[i] = lams[i] > 0 ? lams[i] : 0; zu[i] = lams[i] < 0 ? -lams[i] : 0; }
@@ -615,7 +615,7 @@ finish:
       for (int j = 0; j < n; ++j) lambda_out[j] = ((w.hl[j] ? zl[j] : 0) - (w.hu[j] ? zu[j] : 0)) / w.E[j];
       for (int r = 0; r < m; ++r) lambda_out[n + r] = ((w.hl[n + r] ? zl[n + r] : 0) - (w.hu[n + r] ? zu[n + r] : 0)) * w.F[r];
     }
-    if ((flag == 0 || flag == 4) && opts.polish) {
+    if ((flag == 0 || flag == 4 || flag == 5) && opts.polish) {
       double* lam = lambda_out;
       if (!lam) {
         lam = (double*)malloc(sizeof(double) * mt);
@@ -624,6 +624,7 @@ finish:
       }
       const int pol_ok = polish(n, m, H, g, A, lb, ub, lbA, ubA, opts.inf_bound, x_out, lam);
       if (flag == 4) flag = pol_ok ? 0 : -1;
+      if (flag == 5) flag = pol_ok ? 0 : 1;
       pol_done = pol_ok;
       if (pol_ok) last_merit = orc_qp_kkt(n, m, H, g, A, lb, ub, lbA, ubA, x_out, lam, opts.inf_bound, 0);
       if (!lambda_out) free(lam);
