@@ -15,7 +15,8 @@
 //       - the operand stream of A~ (written once by qp_prep_kernel, qp_solver.hip) is copied into LDS once per QP when
 //         it fits (RES; kinematic shapes, 93 KB for N = 40), otherwise the passes read it from global memory;
 //   * pass 1 (M = H~ + A~'DA~ on the matrix cores) is split by tiles: the upper tiles of M are dealt round-robin to
-//     the W wavefronts, NT/W accumulator tiles each (no spills up to T = 12, nV <= 196);
+//     the W wavefronts, NT/W accumulator tiles each (T up to 12, nV <= 196; the accumulators fit, the row state of the large shapes does not:
+//     the T = 8 instantiation spills 597 VGPRs at nC = 1200);
 //   * the matrix-vector passes are split by slots: the wave that owns a slot also streams its 16 k-steps, so their
 //     results land in the registers of the owner lane and never leave the wave;
 //   * blocked right-looking Cholesky over the distributed tiles: diagonal tile in one wave (four 4-row panels on the
