@@ -527,6 +527,11 @@ def test_closed_loop_monte_carlo_abnormal_exits(fm, torch_, model):
     assert n_act >= 0.8 * fl.size
     assert not ((fl == -3) & ac).any()
     assert ((fl == -1) & ac).sum() <= (0.001 if model == 0 else 0.025) * n_act, np.unique(fl[ac], return_counts=True)
+    # -1 before the first iteration = NaN / Inf in the QP data (linearisation of the dynamic model about a plan whose speed
+    # collapsed; the reference's MEX gateway rejects such calls).  What remains are real misses of the solver: below 0.3 %
+    # (measured 0.07 % over 200 steps of 2048 cars)
+    real_miss = ((fl == -1) & (it > 0) & ac).sum()
+    assert real_miss <= 0.003 * n_act, (int(real_miss), n_act)
     abnormal = 1.0 - ((fl == 0) & ac).sum() / n_act
     assert abnormal <= (0.01 if model == 0 else 0.12), (abnormal, np.unique(fl[ac], return_counts=True))
     assert np.isfinite(cl.cart.cpu().numpy()[(cl.finished == 0).cpu().numpy()]).all()
