@@ -16,7 +16,7 @@
 //         it fits (RES; kinematic shapes, 93 KB for N = 40), otherwise the passes read it from global memory;
 //   * pass 1 (M = H~ + A~'DA~ on the matrix cores) is split by tiles: the upper tiles of M are dealt round-robin to
 //     the W wavefronts, NT/W accumulator tiles each (T up to 12, nV <= 196; the accumulators fit, the row state of the large shapes does not:
-//     the T = 8 instantiation spills 597 VGPRs at nC = 1200);
+//     the T = 8 instantiation spills 473 VGPRs at nC = 1200);
 //   * the matrix-vector passes are split by slots: the wave that owns a slot also streams its 16 k-steps, so their
 //     results land in the registers of the owner lane and never leave the wave;
 //   * blocked right-looking Cholesky over the distributed tiles: diagonal tile in one wave (four 4-row panels on the
@@ -1295,6 +1295,7 @@ template <int T, int NB> static hipError_t launch_stream(const QpParams& P, int 
 #endif
   if (JT <= 16) return launch_wg<T, NB, 8, 2, false>(P, batch, st);
 #ifndef QP_WG_DEV
+  if (T >= 8 && JT <= 24) return launch_wg<T, NB, 8, 3, false>(P, batch, st);   // three slots per wave: 12 fewer doubles of row state per lane
   if (JT <= 32) return launch_wg<T, NB, 8, 4, false>(P, batch, st);
 #endif
   return hipErrorInvalidValue;
