@@ -3,7 +3,7 @@
 plus a timing A/B against the round-1 kernel (FSAEMPC_QP_V1=1 in a child process)."""
 import os, subprocess, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import fsae_mpc_amd as fm
 import oracle as orc

@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import torch, fsae_mpc_amd as fm, oracle as orc
 tr = fm.Track.load("fsg2019"); otr = orc.Track.load(os.path.join('fsae-mpc_amd','tracks','fsg2019.json'))
 model = fm.KINEMATIC if (len(sys.argv) < 2 or sys.argv[1] == 'kin') else fm.DYNAMIC

@@ -4,7 +4,7 @@ LDS dumped to P.dump, s_endpgm at a chosen basic block) are run on ONE instance;
 usage: frag_dump.py child <out.npz>   |   frag_dump.py cmp <libA> <libB> [label]"""
 import ctypes as C, os, subprocess, sys
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..")
 sys.path.insert(0, ROOT)
 MODEL, N = 0, int(os.environ.get("FRAG_N", "39"))
 VEC = ["X", "G", "HX", "R1", "R2", "P1", "P2", "P3", "DX", "E"]

@@ -3,7 +3,7 @@
 iterate is always returned).  usage: frag_iter.py child <out.npz>   |   frag_iter.py cmp <libA> <libB>"""
 import os, subprocess, sys
 import numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..")
 sys.path.insert(0, ROOT)
 MODEL, N, B, K = 0, int(os.environ.get("FRAG_N", "39")), 8, int(os.environ.get("FRAG_K", "4"))
 

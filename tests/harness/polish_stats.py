@@ -2,7 +2,7 @@
 """Polish diagnostics on the GPU: accepted fraction, x error against the oracle's LU polish, KKT certificate."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import fsae_mpc_amd as fm
 import oracle as orc

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Solves the QPs stored by `tools/cl_failures_check.py --save f.npz` again on the GPU, one at a time, and with the oracle.
-usage: tools/solve_saved_qps.py f.npz [key-prefix]"""
+usage: tests/harness/solve_saved_qps.py f.npz [key-prefix]"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import fsae_mpc_amd as fm
 import oracle as orc
