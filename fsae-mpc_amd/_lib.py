@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("FSAEMPC_LIB") or os.path.join(_HERE, "lib", "libfsaem
 EXPORTS = [
     "fsaempc_qp_default_opts", "fsaempc_qp_workspace_bytes", "fsaempc_qp_solve_batch_device", "fsaempc_qp_solve_batch",
     "fsaempc_ltv_nx", "fsaempc_ltv_nV", "fsaempc_ltv_nC", "fsaempc_ltv_build_qp_batch_device",
-    "fsaempc_ltv_workspace_bytes", "fsaempc_ltv_step_batch_device", "fsaempc_last_error", "fsaempc_selftest_mfma",
+    "fsaempc_ltv_workspace_bytes", "fsaempc_ltv_step_batch_device", "fsaempc_ltv_step_batch_device_aux", "fsaempc_last_error", "fsaempc_selftest_mfma",
     "fsaempc_debug_set_dump", "fsaempc_qp_solve_batch_device_aux", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
     "fsaempc_seq_init", "fsaempc_seq_hotstart", "fsaempc_seq_hotstart_matrices", "fsaempc_seq_equality", "fsaempc_seq_cleanup",
     "fsaempc_obtain_reference_batch_device", "fsaempc_reference_live_batch_device",
@@ -66,6 +66,7 @@ def lib():
         L.fsaempc_qp_solve_batch.argtypes = [C.POINTER(QpDesc)] + [vp] * 7 + [C.POINTER(QpOpts)] + [vp] * 5
         L.fsaempc_ltv_build_qp_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [vp] * 7 + [vp] * 3 + [vp]
         L.fsaempc_ltv_step_batch_device.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [C.POINTER(QpOpts)] + [vp] * 6 + [vp, ll, vp]
+        L.fsaempc_ltv_step_batch_device_aux.argtypes = [C.POINTER(LtvDesc), C.POINTER(Spline)] + [vp] * 4 + [C.POINTER(QpOpts)] + [vp] * 6 + [C.POINTER(QpAux), vp, ll, vp]
         L.fsaempc_obtain_reference_batch_device.argtypes = [vp, C.c_double, C.c_int, vp, vp, C.c_double, C.c_int, C.c_int, vp, vp]
         L.fsaempc_reference_live_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp, vp]
         L.fsaempc_cl_pre_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.POINTER(Spline), vp, vp, C.c_int, vp, vp, vp, vp]

@@ -337,6 +337,13 @@ int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_sp
                                   const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
                                   const fsaempc_qp_opts* opts, double* u_opt, double* x_opt, double* slack, double* fval,
                                   int* exitflag, int* iter, void* workspace, long long workspace_bytes, void* stream) {
+  return fsaempc_ltv_step_batch_device_aux(desc, sp, x0, x_ref, x_lin, u_lin, opts, u_opt, x_opt, slack, fval, exitflag, iter, nullptr, workspace, workspace_bytes, stream);
+}
+
+int fsaempc_ltv_step_batch_device_aux(const fsaempc_ltv_desc* desc, const fsaempc_spline* sp,
+                                      const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                                      const fsaempc_qp_opts* opts, double* u_opt, double* x_opt, double* slack, double* fval,
+                                      int* exitflag, int* iter, const fsaempc_qp_aux* aux, void* workspace, long long workspace_bytes, void* stream) {
   int rc = ltv_check(desc, sp); if (rc) return rc;
   if (!x0 || !x_ref || !x_lin || !u_lin || !u_opt || !x_opt || !slack || !fval || !exitflag || !iter || !workspace) return fail(FSAEMPC_ERR_ARG, "null argument");
   if (fsaempc_ltv_nV(desc->model, desc->N) > FSAEMPC_MAX_NV) return fail(FSAEMPC_ERR_DIM, "nV exceeds FSAEMPC_MAX_NV");
@@ -349,8 +356,8 @@ int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_sp
                                          D(c.pred), D(c.Bt), D(c.qc), stream);
   if (rc) return rc;
   fsaempc_qp_desc q{fsaempc_ltv_nV(desc->model, desc->N), fsaempc_ltv_nC(desc->model, desc->N), desc->batch, 0};
-  rc = fsaempc_qp_solve_batch_device(&q, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA), opts, D(c.z), fval, exitflag, iter,
-                                     nullptr, w + c.qpws, (long long)(c.total - c.qpws), stream);
+  rc = fsaempc_qp_solve_batch_device_aux(&q, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA), opts, D(c.z), fval, exitflag, iter,
+                                         nullptr, aux, w + c.qpws, (long long)(c.total - c.qpws), stream);
   if (rc) return rc;
   hipError_t e = ltv_post_launch(fsaempc_ltv_nx(desc->model), desc->N, ltv_ns(desc->model), desc->batch, D(c.z), D(c.pred), D(c.Bt), D(c.qc),
                                  u_opt, x_opt, slack, fval, (hipStream_t)stream);

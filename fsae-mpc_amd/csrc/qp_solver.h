@@ -47,7 +47,7 @@ int qp_selftest_mfma(char* msg, int msglen);
 #define QP_WG_NVEC_FIXED 14   /* X G HX P1 P2 P3 DX E R1 R2 + DV W1V W2V LV */
 inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk, bool res) {
   const size_t JS = (size_t)d.J * 64;
-  return ((size_t)(QP_WG_NVEC_FIXED + 2 * NBk) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + (size_t)W * 96 +
+  return ((size_t)(QP_WG_NVEC_FIXED + 2 * NBk) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + 256 + (size_t)W * 96 +
           (size_t)2 * 8 * W + (6 + (res ? (size_t)NBk : 0)) * JS) * sizeof(double);
 }
 

@@ -878,8 +878,23 @@ template <int T, int K, bool RHS> struct FactorStep {
     tile_store(k, YL + K * 272, Yk);          // U_KK^-T stays in LDS for the solves of this iteration
     WAVE_SYNC();
     const v4d Wk = tile_load_t(k, YL + K * 272);   // U_KK^-1
+    // U_KJ = U_KK^-T M_KJ through the explicit inverse, then one step of refinement against U_KK itself:
+    // U_KJ += U_KK^-T (M_KJ - U_KK' U_KJ).  The product with the explicit inverse alone leaves a backward error of
+    // cond(U_KK) eps in the block row (measured on the normal matrix of kinematic N = 40 id 6585 at iteration 14,
+    // cond(U_00) = 6e7: |M - U'U| / |M| = 1.8e-14 against 1e-15 for a substitution; the refined row reaches 7e-16), which
+    // reappears as noise in the dual residual of the next iterate (10x the CPU oracle's) and jams the end game.
+    const v4d& UKK = acc[Tri<T>::idx(K, K)];
 #pragma unroll
-    for (int Jt = K + 1; Jt < T; ++Jt) acc[Tri<T>::idx(K, Jt)] = mfma4_new(Wk, acc[Tri<T>::idx(K, Jt)]);   // U_KJ = U_KK^-T M_KJ
+    for (int Jt = K + 1; Jt < T; ++Jt) {
+      v4d Rr = acc[Tri<T>::idx(K, Jt)];
+      v4d Ukj = mfma4_new(Wk, Rr);
+#ifndef QP_NO_ROW_REFINE
+      mfma4_sub<T>(UKK, Ukj, Rr);                                                   // M_KJ - U_KK' U_KJ
+#pragma unroll
+      for (int p = 0; p < 4; ++p) Ukj = __builtin_amdgcn_mfma_f64_16x16x4f64(Wk[p], Rr[p], Ukj, 0, 0, 0);
+#endif
+      acc[Tri<T>::idx(K, Jt)] = Ukj;
+    }
 #pragma unroll
     for (int I = K + 1; I < T; ++I) {
       const v4d& UKI = acc[Tri<T>::idx(K, I)];
@@ -1477,6 +1492,12 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
     fval_s = fval; merit_s = merit;
     const bool res_ok = merit <= P.tol;
+#ifdef QP_DEBUG_DUMP
+    if (P.dump && P.dump_stage == 5 && b == P.dump_iter && lane == 0 && it < 120) {   // debug: iteration trace of instance `dump_iter`
+      double* o_ = P.dump + 16 * it;
+      o_[0] = merit; o_[1] = rd_rel; o_[2] = rp_rel; o_[3] = gap_rel; o_[4] = mu; o_[5] = fval; o_[6] = (double)have_saved; o_[7] = saved_merit;
+    }
+#endif
     if (!(merit < INFINITY)) { flag = have_saved ? 2 : -1; break; }
     if (merit <= P.tol_loose && merit < saved_merit) {
       for (int i = lane; i < k.np; i += 64) XS[i] = X[i];
@@ -1669,6 +1690,10 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       alpha = fmin(1.0, fmin(0.99999999 * amax_w, fmax(a_h, gamma_f * amax_w)));
     }
 #ifdef QP_DEBUG_DUMP
+    if (P.dump && P.dump_stage == 5 && b == P.dump_iter && lane == 0 && it < 120) {
+      double* o_ = P.dump + 16 * it;
+      o_[8] = a_aff; o_[9] = sigma; o_[10] = alpha; o_[11] = cw; o_[12] = amax_w; o_[13] = (double)stall;
+    }
     if (P.dump && b == 0 && P.dump_stage == 4 && it == P.dump_iter) {   // debug: step-length pipeline of this iteration
       double c1 = 0, c2 = 0, c3 = 0, c4 = 0;
       for (int js = 0; js < JT; ++js) { const int ix = js * 64 + lane; c1 += aVA[ix]; c2 += aVC[ix]; c3 += aW2[ix]; c4 += aW1[ix]; }
@@ -1761,6 +1786,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   // could not (rejected 10-20 % of the instances).  One fused stream over A~ per CG step (q = A_W w and A_W'q together),
   // A'p kept by recurrence.  The result is accepted only if a fresh evaluation says it is a KKT point of the full QP;
   // otherwise the interior-point iterate is returned.
+#ifdef QP_DEBUG_DUMP
+  if (P.dump && P.dump_stage == 5 && b == P.dump_iter && lane == 0) { double* o_ = P.dump + 16 * 120; o_[4] = (double)flag; for (int i_ = 5; i_ < 48; ++i_) o_[i_] = 0.0; }
+#endif
   if ((flag == 0 || flag == 4 || flag == 5) && P.polish) {
     const double rho = 1e6, pin = 1e16, rinv = 1.0 / rho;
     double* PA = rowp(k, R_CB1); double* PB = rowp(k, R_RPL); double* PY = rowp(k, R_CC1); double* PS = rowp(k, R_CB2);
@@ -1942,6 +1970,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const double f2 = wave_sum(fl2);
 #ifdef QP_DEBUG_DUMP
       if (P.dump && b < 32 && P.dump_stage == 3 && lane == 0) { double* o_ = P.dump + 64 * b; o_[0] = m_rd; o_[1] = m_rp; o_[2] = m_sg; o_[3] = m_cp; o_[5] = f2; }
+      if (P.dump && P.dump_stage == 5 && b == P.dump_iter && lane == 0 && attempt < 8) { double* o_ = P.dump + 16 * 120 + 8 + 5 * attempt; o_[0] = 1.0; o_[1] = m_rd; o_[2] = m_rp; o_[3] = m_sg; o_[4] = m_cp; }
 #endif
       // acceptance: relative stationarity 1e-8 (the 1e8 slack cost of ltvmpc_*.m:35 puts cancellations of 1e8 eps into A'y of
       // the active soft rows: the floor of any fp64 evaluation of this residual; qpOASES' own terminationTolerance is
@@ -2027,6 +2056,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   }
   STAMP(13);
   STAMP_OUT;
+#ifdef QP_DEBUG_DUMP
+  if (P.dump && P.dump_stage == 5 && b == P.dump_iter && lane == 0) { double* o_ = P.dump + 16 * 120; o_[0] = (double)flag; o_[1] = (double)it; o_[2] = (double)flag_polished; o_[3] = merit_s; }
+#endif
   if (lane == 0) {
     P.fval[b] = fval_s;
     P.exitflag[b] = flag;

@@ -190,7 +190,8 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   constexpr int oPB = oYL + T * 272;           // T panel-row tiles in register image [p][lane]; outside the factorisation:
                                                //   W partial n-vectors of H~ z (T*256 >= W*np for every T)
   constexpr int oWP = oPB;                     // W partial n-vectors of A'w products: same region (never live together with the above)
-  constexpr int oScr = oPB + T * 256;          // per-wave scratch [6][16]
+  constexpr int oUK = oPB + T * 256;           // register image of the diagonal factor tile U_KK of the current block step
+  constexpr int oScr = oUK + 256;              // per-wave scratch [6][16]
   constexpr int oRed = oScr + W * 96;          // reduction scratch: 2 buffers x 8 values x W
   constexpr int oEx = oRed + 2 * 8 * W;        // per-row exchange: [slot][6 arrays (+ NB border columns of A~ when RES)][64]
   constexpr int EXS = (6 + (RES ? NB : 0)) * 64;   // doubles per slot
@@ -719,6 +720,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
           for (int p = 0; p < 4; ++p) Yk[p] = (q + 4 * p == c) ? 1.0 : 0.0;
           fbad |= diag_factor(c, q, acc[t], Yk, floor_abs);
           tile_store17(oYL + K * 272, Yk);               // U_KK^-T stays in LDS for the solves of this iteration
+          img_store(oUK, acc[t]);                        // U_KK itself: the block row is refined against it
         }
       __syncthreads();
       // B: block row K: U_KJ = U_KK^-T M_KJ -> panel images; y_K = U_KK^-T b_K formed by every wave of the row; b_J -= U_KJ' y_K
@@ -728,12 +730,19 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
         for (int t = 0; t < NTW; ++t) need = need || (tI[t] == K && tJ[t] < T);
         if (need) {
           const v4d Wk = tile_load17_t(oYL + K * 272);             // U_KK^-1 as the A operand acts as U_KK^-T
+          const v4d Ukk = img_load(oUK);
           const v4d yk = mfma4_new(Wk, rhs_load(K, vo, NS));
 #pragma unroll
           for (int t = 0; t < NTW; ++t) {
             if (tI[t] == K && tJ[t] == K) { ydef = yk; kdef = K; }
             if (tI[t] == K && tJ[t] > K && tJ[t] < T) {
-              acc[t] = mfma4_new(Wk, acc[t]);
+              // U_KJ = U_KK^-T M_KJ through the explicit inverse + one step of refinement against U_KK (see FactorStep in
+              // qp_solver.hip: the unrefined row carries a backward error of cond(U_KK) eps)
+              v4d Rr = acc[t];
+              acc[t] = mfma4_new(Wk, Rr);
+              mfma4_sub(Ukk, acc[t], Rr);
+#pragma unroll
+              for (int p = 0; p < 4; ++p) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wk[p], Rr[p], acc[t], 0, 0, 0);
               img_store(oPB + tJ[t] * 256, acc[t]);
               rhs_sub(tJ[t], vo, NS, mfma4_new(acc[t], yk));
             }

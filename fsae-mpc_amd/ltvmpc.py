@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import LtvDesc, QpDesc, Spline, check, default_opts, lib
+from ._lib import LtvDesc, QpAux, QpDesc, Spline, check, default_opts, lib
 from .synthetic import DYNAMIC, KINEMATIC
 
 
@@ -54,8 +54,9 @@ class LtvBatch:
         check(rc, "fsaempc_ltv_build_qp_batch_device")
         return q
 
-    def step(self, x0, x_ref, x_lin, u_lin, stream=None):
-        """Fused step.  Returns dict(u_opt (B,2N), x_opt (B,nx*N), slack (B,ns), fval, exitflag, iter)."""
+    def step(self, x0, x_ref, x_lin, u_lin, stream=None, want_aux=False):
+        """Fused step.  Returns dict(u_opt (B,2N), x_opt (B,nx*N), slack (B,ns), fval, exitflag, iter); want_aux adds the solve's
+        per-instance diagnostics `kkt` (achieved relative KKT residual) and `polished` (> 0: the returned point is the vertex)."""
         torch = self.torch
         B = self.batch
         need = lib().fsaempc_ltv_workspace_bytes(C.byref(self.desc))
@@ -66,10 +67,14 @@ class LtvBatch:
         out = dict(u_opt=self._f64(B, 2 * self.N), x_opt=self._f64(B, self.nx * self.N), slack=self._f64(B, self.ns), fval=self._f64(B),
                    exitflag=torch.empty(B, dtype=torch.int32, device=self.device), iter=torch.empty(B, dtype=torch.int32, device=self.device))
         P = lambda t: C.c_void_p(t.data_ptr())
-        rc = lib().fsaempc_ltv_step_batch_device(C.byref(self.desc), C.byref(self.sp), P(x0), P(x_ref), P(x_lin), P(u_lin), C.byref(self.opts),
-                                                 P(out["u_opt"]), P(out["x_opt"]), P(out["slack"]), P(out["fval"]), P(out["exitflag"]), P(out["iter"]),
-                                                 P(self._ws), C.c_longlong(self._ws.numel() * 8), self._stream(stream))
-        check(rc, "fsaempc_ltv_step_batch_device")
+        if want_aux:
+            out["kkt"] = self._f64(B)
+            out["polished"] = torch.empty(B, dtype=torch.int32, device=self.device)
+        aux = QpAux(P(out["kkt"]), P(out["polished"])) if want_aux else QpAux(None, None)
+        rc = lib().fsaempc_ltv_step_batch_device_aux(C.byref(self.desc), C.byref(self.sp), P(x0), P(x_ref), P(x_lin), P(u_lin), C.byref(self.opts),
+                                                     P(out["u_opt"]), P(out["x_opt"]), P(out["slack"]), P(out["fval"]), P(out["exitflag"]), P(out["iter"]),
+                                                     C.byref(aux), P(self._ws), C.c_longlong(self._ws.numel() * 8), self._stream(stream))
+        check(rc, "fsaempc_ltv_step_batch_device_aux")
         return out
 
 

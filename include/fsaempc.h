@@ -192,6 +192,16 @@ int fsaempc_ltv_step_batch_device(const fsaempc_ltv_desc* desc, const fsaempc_sp
                                   double* u_opt, double* x_opt, double* slack, double* fval, int* exitflag, int* iter,
                                   void* workspace, long long workspace_bytes, void* stream);
 
+/* Same step with the per-instance diagnostics of the solve (fsaempc_qp_aux: achieved KKT residual, refinement outcome);
+ * aux may be NULL.  The reference's drivers hand back the solver object `QP` at this position of their output list
+ * (ltvmpc_*.m:1); a batched build has no such object, the diagnostics take its place. */
+int fsaempc_ltv_step_batch_device_aux(const fsaempc_ltv_desc* desc, const fsaempc_spline* sp,
+                                      const double* x0, const double* x_ref, const double* x_lin, const double* u_lin,
+                                      const fsaempc_qp_opts* opts,
+                                      double* u_opt, double* x_opt, double* slack, double* fval, int* exitflag, int* iter,
+                                      const fsaempc_qp_aux* aux,
+                                      void* workspace, long long workspace_bytes, void* stream);
+
 /* ---- reference trajectories ---------------------------------------------------------------- */
 
 /*

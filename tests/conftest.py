@@ -31,8 +31,15 @@ def otrack(orc, track_path):
 
 
 def golden_files():
+    """LTV-MPC instance fixtures (inputs, QP, certified solution; tests/harness/make_golden.py)."""
     d = os.path.join(ROOT, "tests", "golden")
-    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".npz"))
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".npz") and not f.startswith("regress_"))
+
+
+def regress_files():
+    """Single QPs an earlier build missed (H, g, A, bounds in the device layout + the certified solution)."""
+    d = os.path.join(ROOT, "tests", "golden")
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".npz") and f.startswith("regress_"))
 
 
 def relerr(a, b):

@@ -316,3 +316,58 @@ def test_track_tables_are_periodic_arclength_splines(name):
     # re-parametrisation is only approximately uniform: segments within 25 % of dl, total length within 5 % of L
     assert np.max(np.abs(seg_len / dl - 1)) < 0.25 and abs(seg_len.sum() / L - 1) < 0.05
     assert np.max(np.abs(speed / dl - 1)) < 0.35
+
+
+# ---- evidence that does not go through the oracle's own checker ("parity unpinned") -------------------------
+@pytest.mark.parametrize("model,N,B", [(0, 40, 6), (1, 40, 4), (1, 60, 3), (1, 80, 2)])
+def test_vertex_recomputed_from_the_working_set_numpy(orc, otrack, model, N, B):
+    """BASELINE sizes (kinematic N = 40: nV 81; dynamic N = 40 / 60 / 80: nV 84 / 124 / 164).  The working set of the oracle's
+    answer (sign pattern of its multipliers, qpOASES.m:58-61) is handed to dense numpy linear algebra, which recomputes the vertex
+    and its multipliers from scratch (tests/kkt_numpy.py: no solver, no oracle code); the recomputed pair must pass the
+    numpy KKT certificate of the FULL QP -- which proves that working set optimal -- and reproduce the oracle's x."""
+    from kkt_numpy import kkt_certificate, vertex_from_working_set
+    x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, range(100, 100 + B))
+    q = orc.build_qp_batch(model, otrack, N, 0.05, x0, xr, xl, ul)
+    o = orc.qp_solve_batch_aux(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"])
+    assert (o["exitflag"] == 0).all()
+    c = kkt_certificate(q["H"], q["g"], q["A"], q["lb"], q["ub"], q["lbA"], q["ubA"], o["x"], o["lam"])
+    assert c["max"].max() <= 1e-6
+    n_checked = 0
+    for b in range(B):
+        if not o["polished"][b]:
+            continue                                                     # an interior-point iterate carries no working set
+        ws = np.where(o["lam"][b] > 0, -1, np.where(o["lam"][b] < 0, 1, 0))
+        # sides that are active with a ZERO multiplier (degenerate vertex) belong to the vertex's working set as well
+        v = np.concatenate([o["x"][b], q["A"][b].T @ o["x"][b]])
+        lo, hi = np.concatenate([q["lb"][b], q["lbA"][b]]), np.concatenate([q["ub"][b], q["ubA"][b]])
+        sc = np.maximum(1.0, np.abs(v))
+        ws_weak = np.where(ws != 0, ws, np.where((lo > -1e9) & (np.abs(v - lo) <= 1e-9 * sc), -1, np.where((hi < 1e9) & (np.abs(hi - v) <= 1e-9 * sc), 1, 0)))
+        for cand in (ws, ws_weak):
+            xv, lv = vertex_from_working_set(q["H"][b].T, q["g"][b], q["A"][b].T, q["lb"][b], q["ub"][b], q["lbA"][b], q["ubA"][b], cand)
+            cv = kkt_certificate(q["H"][b:b + 1], q["g"][b:b + 1], q["A"][b:b + 1], q["lb"][b:b + 1], q["ub"][b:b + 1], q["lbA"][b:b + 1],
+                                 q["ubA"][b:b + 1], xv[None], lv[None])
+            if cv["max"][0] <= 1e-9:
+                break
+        assert cv["max"][0] <= 1e-9, (b, {k: float(cv[k][0]) for k in ("stationarity", "primal", "sign", "complementarity")})
+        assert np.abs(xv - o["x"][b]).max() <= 1e-7 * max(1.0, np.abs(xv).max()), b
+        n_checked += 1
+    assert n_checked >= max(1, B // 2)
+
+
+@pytest.mark.parametrize("model,N,inst", [(0, 40, 3)])
+def test_solution_vs_scipy_at_the_headline_size(orc, otrack, model, N, inst):
+    """scipy trust-constr on one QP of the headline shape (kinematic N = 40, nV = 81, nC = 240; about a minute).  The dynamic
+    BASELINE sizes take 10-40 minutes per instance with this solver: they were run once, tests/harness/scipy_crosscheck.py,
+    results in profiles/round3/scipy_crosscheck.json."""
+    from scipy.optimize import Bounds, LinearConstraint, minimize
+    x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, [inst])
+    q = orc.build_qp(model, otrack, N, 0.05, x0[0], xr[0].T, xl[0].T, ul[0].T)
+    H, g, A = q["H"], q["g"], q["A"]
+    x, f, fl, it, lam = orc.qp_solve(H, g, A, q["lb"], q["ub"], q["lbA"], q["ubA"])
+    assert fl == 0
+    lbA = np.where(q["lbA"] < -1e9, -np.inf, q["lbA"]); ubA = np.where(q["ubA"] > 1e9, np.inf, q["ubA"])
+    res = minimize(lambda z: 0.5 * z @ H @ z + g @ z, np.clip(x * 0, q["lb"], np.minimum(q["ub"], 1e3)), jac=lambda z: H @ z + g, hess=lambda z: H,
+                   method="trust-constr", bounds=Bounds(q["lb"], q["ub"]), constraints=[LinearConstraint(A, lbA, ubA)],
+                   options=dict(gtol=1e-10, xtol=1e-12, barrier_tol=1e-12, maxiter=5000))
+    assert abs(res.fun - f) <= 1e-8 * max(1.0, abs(f))
+    assert np.max(np.abs(res.x - x)) <= 1e-6 * max(1.0, np.max(np.abs(x)))
