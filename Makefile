@@ -29,27 +29,29 @@ $(LIBDIR)/qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h $(C
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
 
-$(LIBDIR)/libfsaempc.so: $(QPOBJ) $(WGOBJ) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+# host-side track pipeline (no device code)
+$(LIBDIR)/track.o: $(CSRC)/track.cpp include/fsaempc.h
+	@mkdir -p $(LIBDIR)
+	g++ -O2 -std=c++17 -fPIC -Wall -Iinclude -c $< -o $@
+
+COMMON := $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o $(LIBDIR)/track.o
+$(LIBDIR)/libfsaempc.so: $(QPOBJ) $(WGOBJ) $(COMMON)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-# diagnostic build with in-kernel phase stamps (never benchmarked; see tools/phase_profile.py)
-stamps: $(LIBDIR)/libfsaempc_stamps.so
-$(LIBDIR)/libfsaempc_stamps.so: $(CSRC)/qp_solver.hip $(CSRC)/qp_wg.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/reference.h include/fsaempc.h
+# development builds of the workgroup kernel: ONE instantiation (T = 8, no border: BASELINE configs[2], dynamic N = 60) linked with the
+# shipped objects of everything else; plain and with phase stamps.  Select with FSAEMPC_LIB.
+WGDEVFLAGS := -DQP_WG_TLO=8 -DQP_WG_THI=8 -DQP_WG_SYM=7 -DQP_WG_ONLY_NB=0
+$(LIBDIR)/wgdev_qp_wg.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DQP_STAMPS=1 -DQP_ONLY_T=5 -DQP_WG_ONE_TU -DQP_WG_TLO=5 -DQP_WG_THI=5 -shared -o $@ $(CSRC)/qp_solver.hip $(CSRC)/qp_wg.hip $(CSRC)/ltv_build.hip $(CSRC)/reference.hip $(CSRC)/plant.hip $(CSRC)/capi.hip
-
-# development build: only T = 5 kernels (headline shapes), plain and with phase stamps; select with FSAEMPC_LIB
-DEVFLAGS := -DQP_ONLY_T=5 -DQP_WG_ONE_TU -DQP_WG_TLO=5 -DQP_WG_THI=5 -DQP_WG_DEV
-$(LIBDIR)/dev_%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h include/fsaempc.h
+	$(HIPCC) $(HIPFLAGS) $(WGDEVFLAGS) -c $< -o $@
+$(LIBDIR)/wgdevst_qp_wg.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(DEVFLAGS) -c $< -o $@
-$(LIBDIR)/devst_%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h include/fsaempc.h
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) $(DEVFLAGS) -DQP_STAMPS=1 -c $< -o $@
-devlib: $(LIBDIR)/libfsaempc_dev.so $(LIBDIR)/libfsaempc_devst.so
-$(LIBDIR)/libfsaempc_dev.so: $(LIBDIR)/dev_qp_solver.o $(LIBDIR)/dev_qp_wg.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+	$(HIPCC) $(HIPFLAGS) $(WGDEVFLAGS) -DQP_STAMPS=1 -c $< -o $@
+WGDEVREST := $(QPOBJ) $(LIBDIR)/qp_wg_1_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o $(COMMON)
+wgdev: $(LIBDIR)/libfsaempc_wgdev.so $(LIBDIR)/libfsaempc_wgdevst.so
+$(LIBDIR)/libfsaempc_wgdev.so: $(LIBDIR)/wgdev_qp_wg.o $(WGDEVREST)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
-$(LIBDIR)/libfsaempc_devst.so: $(LIBDIR)/dev_qp_solver.o $(LIBDIR)/devst_qp_wg.o $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+$(LIBDIR)/libfsaempc_wgdevst.so: $(LIBDIR)/wgdevst_qp_wg.o $(WGDEVREST)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # diagnostic library with the in-kernel dump hooks of both kernels (tests/test_gpu_parity.py::test_01_normal_matrix_dump_matches_numpy); T <= 5
@@ -61,7 +63,7 @@ $(LIBDIR)/dbg_qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_DEBUG_DUMP -DQP_TU=$*
 dbg: $(LIBDIR)/libfsaempc_dbg.so
-$(LIBDIR)/libfsaempc_dbg.so: $(DBGOBJ) $(LIBDIR)/qp_solver_tu3.o $(LIBDIR)/qp_solver_tu4.o $(filter-out $(LIBDIR)/qp_wg_1_5.o,$(WGOBJ)) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+$(LIBDIR)/libfsaempc_dbg.so: $(DBGOBJ) $(LIBDIR)/qp_solver_tu3.o $(LIBDIR)/qp_solver_tu4.o $(filter-out $(LIBDIR)/qp_wg_1_5.o,$(WGOBJ)) $(COMMON)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # guard build: the solver sources at -O1, every instantiated (T, NB) (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build
@@ -76,7 +78,7 @@ $(LIBDIR)/o1_qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h 
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(O1FLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
 o1: $(LIBDIR)/libfsaempc_O1.so
-$(LIBDIR)/libfsaempc_O1.so: $(O1OBJ) $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR)/capi.o
+$(LIBDIR)/libfsaempc_O1.so: $(O1OBJ) $(COMMON)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 isa-report:
@@ -88,4 +90,4 @@ oracle:
 clean:
 	rm -rf $(LIBDIR)/*.o $(LIBDIR)/*.so $(LIBDIR)/*.isa.log $(LIBDIR)/*.s
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean stamps o1 devlib dbg isa-report
+.PHONY: all oracle clean o1 wgdev dbg isa-report

@@ -84,14 +84,25 @@ def main():
     qp_args = [q[k] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")]
     ws = None
     L = fm.lib()
+    # the only exchange: every rank's (x, fval, exitflag, iter) as ONE preallocated (B/G) x (nV + 2) block, one
+    # all_gather_into_tensor per step over RCCL/xGMI; buffers are allocated here, outside the timed region
+    gather = shard.ResultGather(Bl, nV, world, "cpu" if rehearsal else dev)
+    gather_ms = []
 
     def step():
         nonlocal ws
         out = fm.qp_solve_batch_device(*qp_args, workspace=ws, want_aux=True)
         ws = out["workspace"]
         if world > 1:
-            xs = out["x"].cpu() if rehearsal else out["x"]
-            out["x_all"] = shard.gather_rows(xs, Btot, rank, world)   # the only exchange: final gather over RCCL/xGMI
+            g0 = time.perf_counter()
+            if rehearsal:
+                gather.pack(out["x"].cpu(), out["fval"].cpu(), out["exitflag"].cpu(), out["iter"].cpu())
+            else:
+                gather.pack(out["x"], out["fval"], out["exitflag"], out["iter"])
+            out["all"] = gather.gather()
+            if not rehearsal:
+                torch.cuda.synchronize(dev)
+            gather_ms.append(1e3 * (time.perf_counter() - g0))   # host-side: includes waiting for this rank's solve
         return out
 
     def barrier():
@@ -125,6 +136,10 @@ def main():
     solved = int(((flags == 0) & (kkt_dev <= TOL_KKT)).sum())   # an instance counts only if it is solved to that tolerance
     n_ok = shard.max_over_ranks(float(-solved), device=rdev)  # min over ranks via max of negatives
     solved_total = shard.sum_over_ranks(float(solved), device=rdev)
+    solved_per_rank = [solved]
+    if world > 1:   # per-rank solved counts from the gathered block itself (exit flag 0), as every rank sees them
+        _, _, fl_all, _ = shard.ResultGather.unpack(out["all"], nV)
+        solved_per_rank = [int((fl_all[r * Bl:(r + 1) * Bl] == 0).sum().item()) for r in range(world)]
     # fused mode of SURVEY 8(d) (x0, x_ref, x_lin, u_lin -> u_opt, x_opt: construction + solve + post-solve), timed
     # separately after the headline loop; reported in `config`, never as `value`
     fx0, fxr, fxl, ful = up(x0), up(xr), up(xl), up(ul)
@@ -185,7 +200,9 @@ def main():
                    "fused_mode_qp_per_s_rank0": fused_rate,
                    "iteration_histogram_rank0": it_hist, "exitflag_histogram_rank0": fl_hist,
                    "max_rel_kkt_rank0": {"stationarity": kkt_max[0], "primal": kkt_max[1], "complementarity": kkt_max[2]},
-                   "parallelism": "instances sharded index-pure over %d GPU(s); RCCL all_gather of x only" % world},
+                   "exitflag0_per_rank": solved_per_rank,
+                   "gather_ms_per_step_rank0": float(np.mean(gather_ms[-args.steps:])) if gather_ms else 0.0,
+                   "parallelism": "instances sharded index-pure over %d GPU(s); one all_gather_into_tensor of the (B/G) x (nV+2) result block (x, fval, exitflag/iter) per step" % world},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved,
                      "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "mfma_busy": None,
                      "flops_per_launch": flops_launch, "algorithmic_bytes_per_solve": bytes_solve,
@@ -241,12 +258,17 @@ def dry_run(args, rank, world):
     from fsae_mpc_amd import shard
     Bl = args.batch
     lo, hi = shard.shard_range(Bl * world, rank, world)
-    x_local = torch.full((hi - lo, 3), float(rank), dtype=torch.float64)
+    nV = 3
+    x_local = torch.full((hi - lo, nV), float(rank), dtype=torch.float64)
+    gather = shard.ResultGather(Bl, nV, world, "cpu")      # the same packed (B/G) x (nV + 2) exchange as the GPU run
+    zf = torch.zeros(Bl, dtype=torch.float64); zi = torch.full((Bl,), rank, dtype=torch.int32)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        x_all = shard.gather_rows(x_local, Bl * world, rank, world) if world > 1 else x_local
+        gather.pack(x_local, zf, torch.zeros(Bl, dtype=torch.int32), zi)
+        blk = gather.gather()
     t_job = shard.max_over_ranks(time.perf_counter() - t0, device="cpu")
-    ok = bool((x_all[lo:hi] == float(rank)).all()) and x_all.shape[0] == Bl * world
+    x_all, _, fl_all, it_all = shard.ResultGather.unpack(blk, nV)
+    ok = bool((x_all[lo:hi] == float(rank)).all()) and x_all.shape[0] == Bl * world and bool((fl_all == 0).all()) and bool((it_all[lo:hi] == rank).all())
     if rank == 0:
         print(json.dumps({"metric": "QP solves/sec (dry run: no solves)", "value": 0.0, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1e3 * t_job / max(1, args.steps), "higher_is_better": True, "scaling": "weak",

@@ -15,6 +15,7 @@ EXPORTS = [
     "fsaempc_seq_init", "fsaempc_seq_hotstart", "fsaempc_seq_hotstart_matrices", "fsaempc_seq_equality", "fsaempc_seq_cleanup",
     "fsaempc_obtain_reference_batch_device", "fsaempc_reference_live_batch_device",
     "fsaempc_cl_pre_batch_device", "fsaempc_cl_plant_batch_device", "fsaempc_cl_accept_batch_device",
+    "fsaempc_track_from_csv", "fsaempc_track_from_points", "fsaempc_track_free", "fsaempc_track_save", "fsaempc_track_load", "fsaempc_track_last_error",
 ]
 
 
@@ -37,6 +38,10 @@ class Spline(C.Structure):
 
 class LtvDesc(C.Structure):
     _fields_ = [("model", C.c_int), ("N", C.c_int), ("batch", C.c_int), ("dt", C.c_double), ("integrator", C.c_int)]
+
+
+class TrackTable(C.Structure):
+    _fields_ = [("M", C.c_int), ("dl", C.c_double), ("L", C.c_double), ("xP", C.POINTER(C.c_double)), ("yP", C.POINTER(C.c_double))]
 
 
 class FsaempcError(RuntimeError):
@@ -73,6 +78,12 @@ def lib():
         L.fsaempc_cl_plant_batch_device.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp, vp, vp, vp]
         L.fsaempc_cl_accept_batch_device.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
         L.fsaempc_debug_set_dump.argtypes = [vp, C.c_int]
+        L.fsaempc_track_last_error.restype = C.c_char_p
+        L.fsaempc_track_from_csv.argtypes = [C.c_char_p, C.c_int, C.POINTER(TrackTable)]
+        L.fsaempc_track_from_points.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(TrackTable)]
+        L.fsaempc_track_free.argtypes = [C.POINTER(TrackTable)]
+        L.fsaempc_track_save.argtypes = [C.POINTER(TrackTable), C.c_char_p]
+        L.fsaempc_track_load.argtypes = [C.c_char_p, C.POINTER(TrackTable)]
         _LIB = L
     return _LIB
 

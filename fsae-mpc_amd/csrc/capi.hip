@@ -68,7 +68,7 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double*
   qp_make_dims(desc->nV, desc->nC, &P.d);
   if ((long long)(P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
   const bool wg = !qp_runs_wavefront_kernel(P.d);
-  if ((wg ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024 || (wg && P.d.J + P.d.JB > 32)) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels (the workgroup kernel supports up to ~1850 constraint rows)");
+  if ((wg ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
   P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr;
@@ -137,9 +137,10 @@ struct SeqQP {
   bool used = false;
   double *dH = nullptr, *dA = nullptr, *dvec = nullptr; void* dws = nullptr; long long wsb = 0;
   std::vector<signed char> wsB, wsC;   // -1 lower / 0 inactive / +1 upper, qpOASES.m:52-62 encoding
+  std::vector<double> hA;              // host copy of A (the working set of a solve is derived on the host: it needs A x)
   void release() {
     (void)hipFree(dH); (void)hipFree(dA); (void)hipFree(dvec); (void)hipFree(dws);
-    dH = dA = dvec = nullptr; dws = nullptr; kcap = 0; wsb = 0; used = false; wsB.clear(); wsC.clear();
+    dH = dA = dvec = nullptr; dws = nullptr; kcap = 0; wsb = 0; used = false; wsB.clear(); wsC.clear(); hA.clear();
   }
 };
 std::mutex g_seq_mu;
@@ -154,6 +155,7 @@ int seq_upload_matrices(SeqQP* q, const double* H, const double* A) {
   if (m && !q->dA) { e = hipMalloc((void**)&q->dA, m * n * sizeof(double)); if (e != hipSuccess) return hipfail(e, "hipMalloc"); }
   e = hipMemcpy(q->dH, H, n * n * sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) return hipfail(e, "hipMemcpy H2D");
   if (m) { e = hipMemcpy(q->dA, A, m * n * sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) return hipfail(e, "hipMemcpy H2D"); }
+  q->hA.assign(A ? A : nullptr, A ? A + m * n : nullptr);
   return 0;
 }
 int seq_solve(SeqQP* q, const double* g, const double* lb, const double* ub, const double* lbA, const double* ubA, int k,
@@ -185,18 +187,35 @@ int seq_solve(SeqQP* q, const double* g, const double* lb, const double* ub, con
   if (rc == 0) rc = fsaempc_qp_solve_batch_device(&d, q->dH, dg, m ? q->dA : nullptr, dlb, dub, m ? dlbA : nullptr, m ? dubA : nullptr, opts,
                                                   dx, dfv, dfl, dit, dlam, q->dws, q->wsb, nullptr);
   if (rc == 0) { e = hipDeviceSynchronize(); if (e != hipSuccess) rc = hipfail(e, "solve"); }
-  std::vector<double> lam0;
+  std::vector<double> lam0, x0h;
   if (rc == 0 && remember && !lambda) lam0.resize(n + m);
+  if (rc == 0 && remember) x0h.resize(n);
 #define BK(dst, src, bytes) do { if (rc == 0 && (dst)) { e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hipfail(e, "hipMemcpy D2H"); } } while (0)
   BK(x, dx, B * n * sizeof(double)); BK(fval, dfv, B * sizeof(double)); BK(exitflag, dfl, B * sizeof(int)); BK(iter, dit, B * sizeof(int));
   BK(lambda, dlam, B * (n + m) * sizeof(double));
   if (!lam0.empty()) BK(lam0.data(), dlam, (n + m) * sizeof(double));
+  if (!x0h.empty()) BK(x0h.data(), dx, n * sizeof(double));
 #undef BK
-  if (rc == 0 && remember) {   // working set of the first column: a side is in it iff its multiplier is non-zero (qpOASES.m:52-62)
+  if (rc == 0 && remember) {
+    // Working set of the first column (qpOASES.m:52-62 encoding), by the rule the kernels' active-set refinement uses: a side is
+    // active iff its multiplier has the side's sign AND exceeds the side's slack.  On a refined vertex that is the same as
+    // "multiplier non-zero"; on an interior-point iterate (refinement rejected or switched off, opts->polish = 0) every finite
+    // side carries a small non-zero multiplier and the sign alone would put all of them into the set.
     const double* l = lambda ? lambda : lam0.data();
     q->wsB.assign(n, 0); q->wsC.assign(m, 0);
-    for (size_t i = 0; i < n; ++i) q->wsB[i] = l[i] > 0 ? -1 : (l[i] < 0 ? 1 : 0);
-    for (size_t i = 0; i < m; ++i) q->wsC[i] = l[n + i] > 0 ? -1 : (l[n + i] < 0 ? 1 : 0);
+    const double ib = opts ? opts->inf_bound : 1e9;
+    for (size_t i = 0; i < n; ++i) {
+      const double v = x0h[i];
+      if (l[i] > 0 && lb[i] > -ib && l[i] > fabs(v - lb[i])) q->wsB[i] = -1;
+      else if (l[i] < 0 && ub[i] < ib && -l[i] > fabs(ub[i] - v)) q->wsB[i] = 1;
+    }
+    for (size_t r = 0; r < m; ++r) {
+      double v = 0.0;
+      for (size_t j = 0; j < n; ++j) v += q->hA[j * m + r] * x0h[j];
+      const double lr = l[n + r];
+      if (lr > 0 && lbA[r] > -ib && lr > fabs(v - lbA[r])) q->wsC[r] = -1;
+      else if (lr < 0 && ubA[r] < ib && -lr > fabs(ubA[r] - v)) q->wsC[r] = 1;
+    }
   }
   return rc;
 }

@@ -4,8 +4,16 @@
 #include <stddef.h>
 
 #define QP_MAX_T 12
-#define QP_WG_RES_MAX_T 5      // tile counts for which the LDS-resident variant (and the 1-column border) of qp_wg.hip is built (development builds)
-#define QP_FLAG_PENDING 99
+#ifndef QP_WG_W
+#define QP_WG_W 8                 // wavefronts per QP of the workgroup kernel
+#endif
+#define QP_WG_NORING_MIN_T 11   // tile counts from which qp_wg.hip also builds the variant without the LDS operand ring (T = 12 with a border does not have the room)
+// an iterate on which the factorisation breaks down gets one try at the active-set refinement if it is this close to primal
+// feasibility and complementarity (both kernels and the oracle: ltv_oracle_qp.c)
+#define QP_BREAKDOWN_TRY_TOL 1e-4
+
+// owner-layout row arrays of the workspace ([array][slot][64], rowlen doubles each; qp_make_dims reserves R_NARR of them)
+enum RowArr { R_L = 0, R_U, R_TL, R_TU, R_ZL, R_ZU, R_V, R_D, R_W1, R_W2, R_W3, R_VA, R_VC, R_RPL, R_RPU, R_CB1, R_CC1, R_CB2, R_CC2, R_NARR };
 
 struct QpDims {
   int n, m;        // variables, general rows
@@ -14,14 +22,18 @@ struct QpDims {
   int Kq, ntr;     // MFMA k-steps = rows per lane group = ceil(m/4); trips of 4 k-steps
   int prep_tw;     // columns staged per pass of the prep kernel's A transpose
   int J, JB;       // owner-layout slots for rows / for variable bounds
-  int ld;          // leading dimension of the LDS normal matrix
+  int nu;          // the CALLER's number of variables.  n above is the solver's: n = nu except when trailing slack columns are kept as
+                   // the border although nu mod 16 is not 1..4 (qp_make_dims): then the core is padded to 16 T columns with dummy
+                   // variables (unit Hessian diagonal, no bounds, zero columns of A: they stay 0) and n = 16 T + nb.  Solver index i is
+                   // real iff i < nu - nb or i >= nc; qp_user_index maps it to the caller's
   int rowlen;      // (J+JB)*64
   size_t off_Aw, off_meta, off_Hw, off_gw, off_E, off_F, off_Ab, off_Hb, off_rows, off_save, off_bad, ws_per_qp;  // in doubles (off_bad: 1.0 if the prep kernel met NaN / Inf in the QP's data)
   size_t lds_solve, lds_prep;                                                  // in bytes
   int W;                  // wavefronts per QP of the workgroup solve kernel (qp_wg.hip)
-  int NBk;                // border width of the kernel variant: 0, 1 (only nb == 1 and T <= QP_WG_RES_MAX_T) or 4
-  size_t lds_aw_bytes;    // LDS reserved for the resident operand stream (0: the passes read it from global memory)
+  int NBk;                // border width of the workgroup kernel's variant: 0 or 4
+  size_t wg_ring;         // workgroup kernel: != 0 if pass 1 reads the operand stream through the LDS ring (the LDS budget has room for it)
   size_t lds_wg;          // total dynamic LDS of the workgroup solve kernel
+  size_t off_U;           // workgroup kernel: the Cholesky factor's tiles as register images [tile][4][64] (read by the solving wave), in doubles
 };
 
 struct QpParams {
@@ -32,22 +44,24 @@ struct QpParams {
   int *exitflag, *iter;
   double tol, tol_loose, tol_x, inf_bound;
   int max_iter, shared_HA, polish;
-  int only_pending;   // workgroup kernel, streaming variant: solve only the instances the resident variant handed over (exit flag QP_FLAG_PENDING)
+  int reserved0;
   int* polished;   // optional per-instance output: >0 if the active-set refinement was accepted (attempt count), <0 reason of rejection
   double* kkt;     // optional per-instance output: relative KKT residual of the returned point as the kernel measured it
   double* dump; int dump_stage, dump_iter;
 };
 
 void qp_make_dims(int n, int m, QpDims* d);
+// solver index -> caller's variable index (-1: dummy padding variable), and back
+__host__ __device__ inline int qp_user_index(const QpDims& d, int i) { const int ncu = d.nu - d.nb; return i < ncu ? i : (i >= d.nc && d.nb > 0 ? ncu + (i - d.nc) : (i < d.nu && d.nb == 0 ? i : -1)); }
+__host__ __device__ inline int qp_solver_index(const QpDims& d, int u) { const int ncu = d.nu - d.nb; return (d.nb > 0 && u >= ncu) ? d.nc + (u - ncu) : u; }
 bool qp_runs_wavefront_kernel(const QpDims& d);   // kernel selection of qp_launch
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid = nullptr);
 int qp_selftest_mfma(char* msg, int msglen);
-// LDS bytes of the workgroup solve kernel (qp_wg.hip) without the resident operand stream; NBk = border width of the
-// kernel variant (0, 1 or 4).  Mirrors the carve at the top of qp_wg_kernel.
+// LDS bytes of the workgroup solve kernel (qp_wg.hip); NBk = border width of the kernel variant (0 or 4), ring = with the
+// operand ring of pass 1.  Mirrors the carve at the top of qp_wg_kernel.
 #define QP_WG_NVEC_FIXED 14   /* X G HX P1 P2 P3 DX E R1 R2 + DV W1V W2V LV */
-inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk, bool res) {
-  const size_t JS = (size_t)d.J * 64;
+inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk, bool ring) {
   return ((size_t)(QP_WG_NVEC_FIXED + 2 * NBk) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + 256 + (size_t)W * 96 +
-          (size_t)2 * 8 * W + (6 + (res ? (size_t)NBk : 0)) * JS) * sizeof(double);
+          (size_t)2 * 8 * W + (size_t)W * 6 * 64 + (size_t)2 * (4 + NBk) * 16 + 16 + (ring ? (size_t)2 * 2 * d.T * 128 : (size_t)W * d.np)) * sizeof(double);
 }
 

@@ -123,10 +123,15 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   // one 256-thread workgroup per QP (4 wavefronts share the LDS staging tile; HBM-bound: ~0.5 MB moved per QP)
   const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
   const QpDims& d = P.d;
-  const int n = d.n, m = d.m, T = d.T, Kq = d.Kq, J = d.J, JB = d.JB, np = d.np, nc = d.nc, nb = d.nb;
-  const double* H = P.H + (P.shared_HA ? 0 : (size_t)b * n * n);
-  const double* A = P.A + (P.shared_HA ? 0 : (size_t)b * m * n);
-  const double* g = P.g + (size_t)b * n;
+  const int n = d.n, nu = d.nu, m = d.m, T = d.T, Kq = d.Kq, J = d.J, JB = d.JB, np = d.np, nc = d.nc, nb = d.nb;
+  const double* H = P.H + (P.shared_HA ? 0 : (size_t)b * nu * nu);
+  const double* A = P.A + (P.shared_HA ? 0 : (size_t)b * m * nu);
+  const double* g = P.g + (size_t)b * nu;
+  // caller's data by SOLVER index (n = nu unless the core is padded with dummy variables, QpDims::nu): dummies have a unit Hessian
+  // diagonal, nothing else
+  auto U = [&](int i) { return qp_user_index(d, i); };
+  auto Hat = [&](int i, int j) -> double { const int ui = U(i), uj = U(j); return (ui >= 0 && uj >= 0) ? H[(size_t)uj * nu + ui] : ((i == j && i < n) ? 1.0 : 0.0); };
+  auto Aat = [&](int r, int j) -> double { const int uj = U(j); return uj >= 0 ? A[(size_t)uj * m + r] : 0.0; };
   double* ws = P.ws + (size_t)b * d.ws_per_qp;
   double* Aw = ws + d.off_Aw;
   double* Hw = ws + d.off_Hw;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   for (int j = tid; j < np; j += 256) {
     double e = 1.0;
     if (j < n) {
-      double hjj = H[(size_t)j * n + j];
+      double hjj = Hat(j, j);
       if (hjj > 1e-12) e = 1.0 / sqrt(hjj);
       else e = -1.0;  // resolved below with a cooperative column max
     } else e = 0.0;   // padded columns carry zeros
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   for (int j = 0; j < n; ++j) {
     if (Esh[j] < 0) {  // uniform over the workgroup
       double cm = 0;
-      for (int r = tid; r < m; r += 256) cm = fmax(cm, fabs(A[(size_t)j * m + r]));
+      for (int r = tid; r < m; r += 256) cm = fmax(cm, fabs(Aat(r, j)));
       cm = wave_max(cm);
       if (lane == 0) red[w] = cm;
       __syncthreads();
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   }
   int bad = 0;   // NaN / Inf anywhere in H, g, A or NaN in a bound: the solve kernel answers -1 before its first iteration (the
                  // reference's MEX gateway rejects such a call; a device entry cannot look at the data before the launch)
-  for (int j = tid; j < np; j += 256) { Es[j] = Esh[j]; gw[j] = j < n ? g[j] * Esh[j] : 0.0; bad |= j < n && !(fabs(g[j]) < INFINITY); }
+  for (int j = tid; j < np; j += 256) { const int uj = j < n ? U(j) : -1; const double gj = uj >= 0 ? g[uj] : 0.0; Es[j] = Esh[j]; gw[j] = gj * Esh[j]; bad |= !(fabs(gj) < INFINITY); }
 
   // ---- row order: class = last core column tile with a nonzero; stable counting sort by class ----
   if (tid < 16) cnt_sh[tid] = 0;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   for (int r = tid; r < m; r += 256) {
     int e = 0;
     for (int col = ncols - 1; col >= 0; --col)
-      if (A[(size_t)col * m + r] != 0.0) { e = col >> 4; break; }
+      if (Aat(r, col) != 0.0) { e = col >> 4; break; }
     cls_sh[r] = e;
     atomicAdd(&cnt_sh[e], 1);
   }
@@ -224,12 +229,12 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     const bool valid = r >= 0;
     double rm = 0;
     if (valid)
-      for (int j = 0; j < n; ++j) rm = fmax(rm, fabs(A[(size_t)j * m + r]) * Esh[j]);
+      for (int j = 0; j < n; ++j) rm = fmax(rm, fabs(Aat(r, j)) * Esh[j]);
     double f = (valid && rm > 1e-12) ? 1.0 / rm : (valid ? 1.0 : 0.0);
     Fs[js * 64 + lane] = f;
     perm_g[js * 64 + lane] = r;
     for (int bb = 0; bb < 4; ++bb)
-    { const double v = (valid && bb < nb) ? A[(size_t)(nc + bb) * m + r] * Esh[nc + bb] * f : 0.0; bad |= !(fabs(v) < INFINITY); Ab[(size_t)bb * J * 64 + js * 64 + lane] = v; }
+    { const double v = (valid && bb < nb) ? Aat(r, nc + bb) * Esh[nc + bb] * f : 0.0; bad |= !(fabs(v) < INFINITY); Ab[(size_t)bb * J * 64 + js * 64 + lane] = v; }
     double l = -INFINITY, u = INFINITY;
     if (valid) {
       double lr = P.lbA[(size_t)b * m + r], ur = P.ubA[(size_t)b * m + r];
@@ -243,8 +248,9 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   for (int jb = w; jb < JB; jb += 4) {
     const int i = jb * 64 + lane;
     double l = -INFINITY, u = INFINITY;
-    if (i < n) {
-      double lr = P.lb[(size_t)b * n + i], ur = P.ub[(size_t)b * n + i];
+    const int ui = i < n ? U(i) : -1;
+    if (ui >= 0) {
+      double lr = P.lb[(size_t)b * nu + ui], ur = P.ub[(size_t)b * nu + ui];
       bad |= (lr != lr) || (ur != ur);
       l = lr > -P.inf_bound ? lr / Esh[i] : -INFINITY;
       u = ur < P.inf_bound ? ur / Esh[i] : INFINITY;
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
         const int cc = e / R4, r = e - cc * R4;
         const int col = 16 * t + c0 + cc;
         double v = 0.0;
-        if (col < nc && col < n && r < m) v = A[(size_t)col * m + r] * Esh[col];
+        if (col < nc && col < n && r < m) v = Aat(r, col) * Esh[col];
         bad |= !(fabs(v) < INFINITY);
         tile[cc * mp1 + r] = v;
       }
@@ -283,13 +289,13 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     const int p = idx & 3, IJ = idx >> 2, I = IJ / T, Jt = IJ - I * T;
     const int row = 16 * I + q + 4 * p, col = 16 * Jt + c;
     double v = 0.0;
-    if (row < nc && col < nc && row < n && col < n) v = H[(size_t)row * n + col] * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
+    if (row < nc && col < nc && row < n && col < n) v = Hat(col, row) * Esh[row] * Esh[col];  // H[col][row] == H[row][col]
     bad |= !(fabs(v) < INFINITY);
     Hw[(size_t)idx * 64 + lane] = v;
   }
   for (int e = tid; e < 4 * np; e += 256) {
     const int bb = e / np, i = e - bb * np;
-    const double v = (bb < nb && i < n) ? H[(size_t)(nc + bb) * n + i] * Esh[nc + bb] * Esh[i] : 0.0;
+    const double v = (bb < nb && i < n) ? Hat(i, nc + bb) * Esh[nc + bb] * Esh[i] : 0.0;
     bad |= !(fabs(v) < INFINITY);
     Hb[e] = v;
   }
@@ -313,7 +319,7 @@ struct Ctx {
   double* Ms;    // LDS n x ld
   double* vec;   // LDS n-vectors, np each
 };
-enum RowArr { R_L = 0, R_U, R_TL, R_TU, R_ZL, R_ZU, R_V, R_D, R_W1, R_W2, R_W3, R_VA, R_VC, R_RPL, R_RPU, R_CB1, R_CC1, R_CB2, R_CC2, R_NARR };
+// (enum RowArr: qp_solver.h, shared with the workgroup kernel)
 enum VecArr { V_X = 0, V_G, V_HX, V_R1, V_R2, V_P1, V_P2, V_P3, V_DX, V_E, V_NARR };   // + 4 border-column vectors MB[b] behind them
 
 DEVINL double* rowp(const Ctx& k, int arr) { return k.rows + (size_t)arr * k.rowlen; }
@@ -1070,7 +1076,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   const int b = blockIdx.x;
   Ctx k;
   const QpDims& d = P.d;
-  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = d.ld;
+  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = 0;
   k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
   double* ws = P.ws + (size_t)b * d.ws_per_qp;
   k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
@@ -1549,7 +1555,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       // the factorisation broke down (weights ~1e24) on an iterate that is nearly primal feasible and complementary: its working
       // set is usually the right one already, so the refinement gets a try -- it accepts nothing that is not a KKT point of the
       // full QP by a fresh evaluation (flag 4 -> 0 if accepted, else -1)
-      if (flag == -1 && P.polish && rp_rel <= 1e-4 && gap_rel <= 1e-4) flag = 4;
+      if (flag == -1 && P.polish && rp_rel <= QP_BREAKDOWN_TRY_TOL && gap_rel <= QP_BREAKDOWN_TRY_TOL) flag = 4;
       break;
     }
     STAMP(6);
@@ -2033,17 +2039,18 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
   }
   if (flag == 4) flag = -1;   // not certified
   if (flag == 5) flag = 1;
-  double* xo = P.x + (size_t)b * n;
-  for (int i = lane; i < n; i += 64) xo[i] = X[i] * EV[i];
+  double* xo = P.x + (size_t)b * d.nu;       // caller's indexing (QpDims::nu: dummy padding variables are skipped)
+  for (int i = lane; i < n; i += 64) { const int ui = qp_user_index(d, i); if (ui >= 0) xo[ui] = X[i] * EV[i]; }
   if (P.lambda) {
-    double* lo = P.lambda + (size_t)b * (n + k.m);
+    double* lo = P.lambda + (size_t)b * (d.nu + k.m);
     for (int jb = 0; jb < k.JB; ++jb) {
       const int i = jb * 64 + lane;
-      if (i < n) lo[i] = aW3[(J + jb) * 64 + lane] / EV[i];
+      const int ui = i < n ? qp_user_index(d, i) : -1;
+      if (ui >= 0) lo[ui] = aW3[(J + jb) * 64 + lane] / EV[i];
     }
     for (int js = 0; js < J; ++js) {
       const int r = k.perm[js * 64 + lane];   // original row of this sorted position
-      if (r >= 0) lo[n + r] = aW3[js * 64 + lane] * Fs[js * 64 + lane];
+      if (r >= 0) lo[d.nu + r] = aW3[js * 64 + lane] * Fs[js * 64 + lane];
     }
   }
   if (!(v_current || flag_polished > 0)) {  // objective at the returned point, in the caller's units (H~,g~ scaling is objective preserving)
@@ -2123,7 +2130,7 @@ template <int T, int NB> __global__ __launch_bounds__(64) void syrk_probe_kernel
   const int b = blockIdx.x;
   Ctx k;
   const QpDims& d = P.d;
-  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = d.ld;
+  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = 0;
   k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
   double* ws = P.ws + (size_t)b * d.ws_per_qp;
   k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
@@ -2162,7 +2169,7 @@ template <int T> __global__ __launch_bounds__(64) void factor_probe_kernel(QpPar
   const int b = blockIdx.x;
   Ctx k;
   const QpDims& d = P.d;
-  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = d.ld;
+  k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = 0;
   k.lane = threadIdx.x; k.c = k.lane & 15; k.q = k.lane >> 4; k.nc = d.nc; k.nb = d.nb;
   double* ws = P.ws + (size_t)b * d.ws_per_qp;
   k.Aw = ws + d.off_Aw; k.Hw = ws + d.off_Hw; k.Ab = ws + d.off_Ab; k.Hb = ws + d.off_Hb;
@@ -2219,18 +2226,33 @@ template <int T> __global__ __launch_bounds__(64) void factor_probe_kernel(QpPar
 #endif
 
 void qp_make_dims(int n, int m, QpDims* d) {
-  d->n = n; d->m = m;
+  d->n = n; d->nu = n; d->m = m;
   // 1..4 trailing variables (the slack columns of the LTV-MPC QPs: nV = 2N + 1 or 2N + 4) are a *border*: they are
   // handled on the VALU instead of costing a whole 16-wide tile row/column of MFMA work and operand traffic
   const int rem = n % 16;
   if (n >= 16 && rem >= 1 && rem <= 4) { d->T = n / 16; d->nb = rem; } else { d->T = (n + 15) / 16; d->nb = 0; }
+  // The slack columns of an LTV-MPC QP are touched by most rows (every soft constraint of every stage), while the input columns of
+  // a row end at its own stage: with the slack columns inside the last core tile every trip of the operand stream reaches all T
+  // tiles and the structural sparsity of the condensed constraints is lost (dynamic N = 60: nV = 124 = 7 x 16 + 12: measured
+  // 10.8 k instead of 4.6 k MFMAs per iteration in pass 1).  Shapes with the row / column signature of the reference's QPs
+  // (kinematic: nC = 6N, nV = 2N + 1; dynamic: nC = 20N, nV = 2N + 4 -- ltvmpc_*.m:38-41, *_state_constraints.m) therefore keep
+  // their 1 / 4 trailing slack columns as the border whatever nV mod 16 is.  A performance policy only: results do not depend on it
+  // (FSAEMPC_SLACK_BORDER=0 switches it off for A/B runs).
+  if (d->nb == 0 && n >= 20) {
+    const char* sb = getenv("FSAEMPC_SLACK_BORDER");
+    const int ns = (m == 10 * (n - 4) && ((n - 4) % 2) == 0) ? 4 : ((m == 3 * (n - 1) && ((n - 1) % 2) == 0) ? 1 : 0);
+    if (ns > 0 && !(sb && sb[0] == '0') && (n - ns + 15) / 16 <= QP_MAX_T) {
+      d->T = (n - ns + 15) / 16; d->nb = ns;
+      d->n = 16 * d->T + ns;     // the solver's variable count: the core padded with dummy variables (qp_solver.h: QpDims::nu)
+    }
+  }
+  n = d->n;
   d->NB = d->nb == 0 ? 0 : (d->nb == 1 ? 1 : 4);
   d->nc = 16 * d->T;
   d->np = d->nc + (d->nb ? 16 : 0);
   d->Kq = (m + 3) / 4;
   d->J = (d->Kq + 15) / 16;
   d->JB = (d->np + 63) / 64;
-  d->ld = n | 1;
   d->rowlen = (d->J + d->JB) * 64;
   size_t off = 0;
   d->ntr = (d->Kq + 3) / 4;   // trips of 4 k-steps (16 rows)
@@ -2246,40 +2268,21 @@ void qp_make_dims(int n, int m, QpDims* d) {
   d->off_rows = off; off += (size_t)R_NARR * d->rowlen;
   d->off_save = off; off += d->np + d->rowlen;
   d->off_bad = off; off += 2;
+  off = (off + 1) & ~(size_t)1;
+  d->off_U = off; off += (size_t)(d->T * (d->T + 1) / 2) * 256;   // (workgroup kernel)
   off = (off + 63) & ~(size_t)63;
   d->ws_per_qp = off;
   {
     d->lds_solve = ((size_t)(V_NARR + (d->NB ? d->NB : 1)) * d->np + (size_t)d->T * 272 + (size_t)(3 * d->T) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);   // ring = StreamCfg<T>::R = 3T records
   }
-  {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP.  The operand stream of A~ stays resident in LDS when
-      // ~2/3 of its dense size fits (structurally empty tiles are skipped, the LTV-MPC families keep ~60 %) and the rows
-      // fit one owner-layout slot per wave; a QP whose stream turns out larger is handed to the streaming variant.
-    const size_t cap = 160 * 1024;
-    const size_t dense = (size_t)2 * d->ntr * d->T * 1024;
-    d->W = 8;
-    d->NBk = d->nb == 0 ? 0 : ((d->nb == 1 && d->T <= QP_WG_RES_MAX_T) ? 1 : 4);
-    d->lds_aw_bytes = 0;
-    const size_t base = qp_wg_lds_base_bytes(*d, d->W, d->NBk, true);
-#ifdef QP_WG_ONE_TU   // the LDS-resident variant exists in development builds only
-    if (base < cap && d->T <= QP_WG_RES_MAX_T && d->J + d->JB <= 8 && dense > 0) {
-      const size_t avail = (cap - base) & ~(size_t)1023;
-      if (dense * 2 / 3 <= avail) d->lds_aw_bytes = dense < avail ? dense : avail;
-    }
-#else
-    (void)cap; (void)dense; (void)base;
-    if (d->NBk == 1) d->NBk = 4;
-#endif
-    d->lds_wg = d->lds_aw_bytes ? base + d->lds_aw_bytes : qp_wg_lds_base_bytes(*d, d->W, d->NBk, false);
-    if (const char* ex = getenv("FSAEMPC_WG")) {   // development only (QP_WG_EXPERIMENT builds): "W,RES"
-      int Wx = 8, Rx = 1;
-      if (sscanf(ex, "%d,%d", &Wx, &Rx) == 2) {
-        d->W = Wx;
-        const size_t bx = qp_wg_lds_base_bytes(*d, Wx, d->NBk, Rx != 0);
-        d->lds_aw_bytes = 0;
-        if (Rx && bx < cap) { const size_t avail = (cap - bx) & ~(size_t)1023; d->lds_aw_bytes = dense < avail ? dense : avail; }
-        d->lds_wg = bx + d->lds_aw_bytes;
-      }
-    }
+  {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP; its pass 1 reads the operand stream through an LDS ring
+      // wherever the 160 KiB budget has room for it (everything but T = 12 with a border)
+    d->W = QP_WG_W;
+    d->NBk = d->nb == 0 ? 0 : 4;
+    const size_t with_ring = qp_wg_lds_base_bytes(*d, d->W, d->NBk, true);
+    d->wg_ring = (with_ring <= 160 * 1024 || d->T < QP_WG_NORING_MIN_T) ? 1 : 0;
+    if (const char* ex = getenv("FSAEMPC_WG_RING")) { if (ex[0] == '0' && d->T >= QP_WG_NORING_MIN_T) d->wg_ring = 0; }   // A/B runs
+    d->lds_wg = qp_wg_lds_base_bytes(*d, d->W, d->NBk, d->wg_ring != 0);
   }
   d->prep_tw = 16;
   for (;;) {

@@ -1,30 +1,29 @@
-// qp_wg.hip -- batched dense convex QP solve on MI355X (gfx950): ONE WORKGROUP of W wavefronts per QP.
+// qp_wg.hip -- batched dense convex QP solve on MI355X (gfx950): ONE WORKGROUP of W wavefronts per QP (nV up to 196).
 //
 // Replaces the qpOASES MEX call of the reference
 //   (mpc/ltv/kinematic/ltvmpc_kinetmatic_curvilinear.m:52, mpc/ltv/dynamic/ltvmpc_dynamic_curvilinear.m:52,
 //    contract optimizers/matlab/qpOASES/qpOASES.m:16-62)
-// with a primal-dual interior-point method (Mehrotra predictor-corrector, single step length, OOQP-style step
-// heuristic).  Not a port of qpOASES: the algorithm is chosen for the hardware.
+// with the same algorithm as the one-wavefront kernel (qp_solver.hip): a primal-dual interior-point method (Mehrotra
+// predictor-corrector, single step length, OOQP-style step heuristic) followed by an active-set refinement that lands on the
+// vertex qpOASES stops at (working set from the multipliers, active bounds pinned, conjugate gradients on the dual of the
+// augmented problem, add / drop corrections, acceptance by a fresh KKT evaluation).  Not a port of qpOASES.
 //
-// Shape of the kernel (round 2; the round-1 kernel ran one wavefront per QP on all 512 registers, spilled, kept every
-// per-row array in global memory and re-streamed A three times per iteration through the L2 / Infinity Cache):
-//   * nothing on the per-iteration path lives in global memory except the Hessian tiles:
-//       - the per-row state (bounds, slacks, multipliers, Gx) sits in REGISTERS of the lane that owns the row
-//         (owner layout: slot js = 64 rows, wave w owns slots w, w+W, ...; SW slots per wave at most),
-//       - what the passes over A~ need per row (weights, corrector coefficients) goes through six LDS arrays,
-//       - the operand stream of A~ (written once by qp_prep_kernel, qp_solver.hip) is copied into LDS once per QP when
-//         it fits (RES; kinematic shapes, 93 KB for N = 40), otherwise the passes read it from global memory;
-//   * pass 1 (M = H~ + A~'DA~ on the matrix cores) is split by tiles: the upper tiles of M are dealt round-robin to
-//     the W wavefronts, NT/W accumulator tiles each (T up to 12, nV <= 196; the accumulators fit, the row state of the large shapes does not:
-//     the T = 8 instantiation spills 473 VGPRs at nC = 1200);
-//   * the matrix-vector passes are split by slots: the wave that owns a slot also streams its 16 k-steps, so their
-//     results land in the registers of the owner lane and never leave the wave;
-//   * blocked right-looking Cholesky over the distributed tiles: diagonal tile in one wave (four 4-row panels on the
-//     matrix cores), U_KK^-T and the panel row U_K* pass through LDS, two barriers per block step with the next
-//     diagonal tile factorised while the others finish their trailing updates; triangular solves: one barrier per block
-//     step (every wave that needs y_K = U_KK^-T b_K forms it itself);
+// Shape of the kernel (round 3; the round-2 version kept the per-row state in registers of owner lanes: 473 spilled VGPRs at
+// nC = 1200, and it had no refinement):
+//   * per-row state (bounds, slacks, multipliers, G x, step products) lives in the workspace's owner-layout row arrays, the
+//     same arrays the one-wavefront kernel uses; a wave sweeps the slots js = w, w + W, ... it owns, one slot (64 rows) of
+//     coalesced loads at a time.  Nothing per-row is kept in registers across phases.
+//   * pass 1 (M = H~ + A~'DA~ on the matrix cores) is split by tiles: the upper tiles of M are dealt round-robin to the W
+//     wavefronts (<= 10 accumulator tiles per wave at T = 12).  The operand stream of A~ goes global memory -> LDS ONCE per
+//     trip (4 k-steps) by LDS-DMA (`global_load_lds_dwordx4`, every wave issues its share of the trip's records) into a
+//     two-chunk ring and is read from there by all waves (one workgroup barrier per trip); the per-row weights of a trip are
+//     staged next to it.  (Round 2: every wave fetched the operand columns of its own tiles with plain global loads.)
+//   * the matrix-vector passes are split by slots: the wave that owns a slot streams its 16 k-steps (operands of the next
+//     pair of k-steps requested before the current pair is consumed), per-row coefficients through a private LDS stage;
+//   * blocked right-looking Cholesky over the distributed tiles (diagonal tile in one wave, four 4-row panels on the matrix
+//     cores; block rows refined against U_KK; U_KK^-T and the panel row pass through LDS; two barriers per block step);
+//     triangular solves: one barrier per block step;
 //   * wave-uniform scalars are reduced through a small LDS scratch so that every wave takes the same branches.
-// No hand-placed s_waitcnt, no LDS-DMA: every cross-wave hand-off is a __syncthreads().
 //
 // Data layout of the workspace: see qp_solver.hip (qp_prep_kernel).  fp64 MFMA lane maps (cdna_hip_programming.md
 // section 3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C/D col = l&15, row = (l>>4) + 4*reg.
@@ -60,9 +59,23 @@ DEVINL double grp16_min(double v) { v = fmin(v, dpp_f64<0xB1>(v)); v = fmin(v, d
 DEVINL double wave_sum(double v) { v = grp16_sum(v); return (rl(v, 0) + rl(v, 16)) + (rl(v, 32) + rl(v, 48)); }
 DEVINL double wave_max(double v) { v = grp16_max(v); return fmax(fmax(rl(v, 0), rl(v, 16)), fmax(rl(v, 32), rl(v, 48))); }
 DEVINL double wave_min(double v) { v = grp16_min(v); return fmin(fmin(rl(v, 0), rl(v, 16)), fmin(rl(v, 32), rl(v, 48))); }
-DEVINL double q_sum(double v) {  // sum over the 4 lane groups (same l&15)
-  v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-  return v;
+// exchange between the four 16-lane rows with the gfx950 lane-swap instructions (see qp_solver.hip)
+struct RowPair { double a, b; };
+DEVINL RowPair rows_xor16(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return {__hiloint2double(h[0], l[0]), __hiloint2double(h[1], l[1])};
+}
+DEVINL RowPair rows_xor32(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return {__hiloint2double(h[0], l[0]), __hiloint2double(h[1], l[1])};
+}
+DEVINL double q_sum(double v) {  // sum over the 4 lane groups (same l&15); every lane gets the total
+  RowPair r = rows_xor16(v); v = r.a + r.b;
+  r = rows_xor32(v); return r.a + r.b;
 }
 
 // LDS n-vectors (np doubles each).  R1, R2 and the NB border-column vectors MB are contiguous: they are the
@@ -151,19 +164,21 @@ DEVINL int diag_factor(int c, int q, v4d& Ud, v4d& Yk, double floor_abs) {
 #define STAMP_OUT do { } while (0)
 #endif
 
-// per-row state in the registers of the owner lane
-struct RowState {
-  double l, u, tl, tu, zl, zu, v;   // scaled bounds (+-inf: no such side), slacks, multipliers, (G x)_row
-  double dl, du;                    // zl/tl, zu/tu of the current iterate
-  double va, vc, wc;                // (G dx_aff)_row, (G dx_cen)_row, (G dx_cor)_row  [vc is reused for the full G dx]
-};
+#ifndef QP_REFINE_ATTEMPTS
+#define QP_REFINE_ATTEMPTS 3
+#endif
+
+// one owner-layout row as the sweeps see it
+struct Row { double l, u, tl, tu, zl, zu, v; };
+template <int C> struct IC { static constexpr int value = C; };
+struct TagKeep { static constexpr bool value = true; };
+struct TagInit { static constexpr bool value = false; };
 
 // ---------------------------------------------------------------------------------------------
-// solve kernel: T column tiles of 16, NB border columns (0, 1 or 4), W wavefronts per QP, at most SW owner-layout
-// slots per wave, RES = operand stream resident in LDS
+// solve kernel: T column tiles of 16, NB border columns (0 or 4), W wavefronts per QP, RING = pass 1 reads the operand
+// stream through the workgroup-shared LDS ring (else straight from global memory: shapes whose LDS budget has no room for it)
 // ---------------------------------------------------------------------------------------------
-// second launch bound = waves per SIMD the register budget must allow: streaming variants with few waves share a CU
-template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(64 * W, (!RES && W <= 4) ? 2 : (W >= 8 ? 2 : 1)) void qp_wg_kernel(QpParams P) {
+template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 : 1) void qp_wg_kernel(QpParams P) {
   constexpr int NT = T * (T + 1) / 2;
   constexpr int NTW = (NT + W - 1) / W;         // accumulator tiles per wave
   constexpr int CW = (T + W - 1) / W;           // column tiles per wave (A'w products of pass 1)
@@ -184,6 +199,14 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   const int* __restrict__ perm = reinterpret_cast<const int*>(ws + d.off_meta);
   const int* __restrict__ tcs = perm + (size_t)(d.J > 0 ? d.J : 1) * 64;
   const int* __restrict__ aoff = tcs + d.ntr;
+  const double* __restrict__ Abg = ws + d.off_Ab;
+  auto rowarr = [&](int a) AINL -> double* { return ws + d.off_rows + (size_t)a * d.rowlen; };
+  double* aL = rowarr(R_L); double* aU = rowarr(R_U);
+  double* aTL = rowarr(R_TL); double* aTU = rowarr(R_TU);
+  double* aZL = rowarr(R_ZL); double* aZU = rowarr(R_ZU);
+  double* aV = rowarr(R_V);
+  double* aD = rowarr(R_D); double* aW1 = rowarr(R_W1); double* aW2 = rowarr(R_W2); double* aW3 = rowarr(R_W3);
+  double* aVA = rowarr(R_VA); double* aVC = rowarr(R_VC); double* aWC = rowarr(R_RPL);   // G dx_aff, G dx_cen (then G dx), G dx_cor
 
   // ---- LDS carve (offsets in doubles; host mirror: qp_wg_lds_base_bytes in qp_solver.h) ----
   constexpr int oYL = V_NARR * np;             // T tiles U_KK^-T, row-major, 17-double rows
@@ -193,10 +216,15 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   constexpr int oUK = oPB + T * 256;           // register image of the diagonal factor tile U_KK of the current block step
   constexpr int oScr = oUK + 256;              // per-wave scratch [6][16]
   constexpr int oRed = oScr + W * 96;          // reduction scratch: 2 buffers x 8 values x W
-  constexpr int oEx = oRed + 2 * 8 * W;        // per-row exchange: [slot][6 arrays (+ NB border columns of A~ when RES)][64]
-  constexpr int EXS = (6 + (RES ? NB : 0)) * 64;   // doubles per slot
-  const int oAw = oEx + J * EXS;               // resident operand stream (RES)
+  constexpr int oCw = oRed + 2 * 8 * W;        // per-wave coefficient stage of the slot passes: [wave][6 arrays][64]
+  constexpr int oC1 = oCw + W * 6 * 64;        // pass 1: per-trip row weights, two buffers of [4 arrays + NB border columns of A~][16]
+  constexpr int C1S = (4 + NB) * 16;
+  constexpr int oUbb = oC1 + 2 * C1S;          // NB x NB factor of the border Schur complement
+  constexpr int oRing = oUbb + 16;             // pass 1 (RING): two chunks of 2T operand records (1 KiB each); outside pass 1
+  constexpr int oP2 = oRing;                   //   (and without RING: W*np doubles) W more partial n-vectors (refinement)
   static_assert(T * 256 >= W * (16 * T + 16), "H~ z partials alias the panel buffer");
+  static_assert(!RING || 2 * 2 * T * 128 >= W * (16 * T + 16), "the second set of partials aliases the ring");
+  static_assert((oRing % 2) == 0 && (oC1 % 2) == 0 && (oCw % 2) == 0, "16-byte aligned LDS arrays");
 #define VEC(a) ((a) * np)
 #define X_(i) slds[VEC(V_X) + (i)]
 #define G_(i) slds[VEC(V_G) + (i)]
@@ -214,8 +242,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
 #define W1V_(i) slds[VEC(V_W1V) + (i)]
 #define W2V_(i) slds[VEC(V_W2V) + (i)]
 #define LV_(i) slds[VEC(V_LV) + (i)]
-#define EX_(a, ix) slds[oEx + ((ix) >> 6) * EXS + (a) * 64 + ((ix) & 63)]
-#define ABL_(e, ix) slds[oEx + ((ix) >> 6) * EXS + (6 + (e)) * 64 + ((ix) & 63)]
+#define CWS_(a, l_) slds[oCw + w * 384 + (a) * 64 + (l_)]
 
   // ---- my accumulator tiles: linear index i = w + W t in the column-major upper triangle (i = J(J+1)/2 + I) ----
   int tI[NTW], tJ[NTW];
@@ -228,30 +255,9 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     tI[t] = i < NT ? i - Jc * (Jc + 1) / 2 : 1 << 20;
   }
 
-  // ---- operand stream: RES = resident in LDS (copied once), else read from global memory by every pass.  A QP whose
-  //      stream does not fit the reserved LDS is handed to the streaming kernel (launched right behind this one) by the
-  //      sentinel exit flag QP_FLAG_PENDING; the streaming kernel in `only_pending` mode skips everything else. ----
-  const int nrec = aoff[ntr];
-  if (RES) {
-    if ((size_t)nrec * 1024 > (size_t)d.lds_aw_bytes) { if (tid == 0) P.exitflag[b] = QP_FLAG_PENDING; return; }
-    for (int r = w; r < nrec; r += W) {
-      const v2d v = *reinterpret_cast<const v2d*>(Awg + (size_t)r * 128 + lane * 2);
-      *reinterpret_cast<v2d*>(&slds[oAw + r * 128 + lane * 2]) = v;
-    }
-  } else if (P.only_pending) {
-    if (P.exitflag[b] != QP_FLAG_PENDING) return;
-  }
-  const double* __restrict__ Abg = ws + d.off_Ab;
-  auto AB_ = [&](int e, int ix) AINL -> double {   // border column e of A~ at owner-layout index ix: LDS copy when RES, else global
-    if constexpr (RES) return ABL_(e, ix); else return Abg[(size_t)e * JS + ix];
-  };
-  auto AB2_ = [&](int e, int ix) AINL -> v2d {     // pair (ix even)
-    if constexpr (RES) return *reinterpret_cast<const v2d*>(&ABL_(e, ix)); else return *reinterpret_cast<const v2d*>(Abg + (size_t)e * JS + ix);
-  };
-  auto opnd = [&](int rec) AINL -> v2d {   // one 1 KB record: lane (c,q) gets its two k-steps
-    if constexpr (RES) return *reinterpret_cast<const v2d*>(&slds[oAw + rec * 128 + lane * 2]);
-    else return *reinterpret_cast<const v2d*>(Awg + (size_t)rec * 128 + lane * 2);
-  };
+  auto AB_ = [&](int e, int ix) AINL -> double { return Abg[(size_t)e * JS + ix]; };   // border column e of A~ at owner-layout index ix
+  auto AB2_ = [&](int e, int ix) AINL -> v2d { return *reinterpret_cast<const v2d*>(Abg + (size_t)e * JS + ix); };
+  auto opnd = [&](int rec) AINL -> v2d { return *reinterpret_cast<const v2d*>(Awg + (size_t)rec * 128 + lane * 2); };   // one 1 KB record: lane (c,q) gets its two k-steps
 
   // ---- workgroup reductions of wave-uniform scalars (double-buffered scratch, one barrier each) ----
   int red_buf = 0;
@@ -269,56 +275,37 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     const double* __restrict__ gw = ws + d.off_gw;
     const double* __restrict__ Es = ws + d.off_E;
     const double* __restrict__ Hb = ws + d.off_Hb;
-    const double* __restrict__ Ab = ws + d.off_Ab;
     for (int i = tid; i < np; i += NTH) {
       G_(i) = gw[i]; EV_(i) = Es[i]; R1_(i) = 0; R2_(i) = 0; DX_(i) = 0; X_(i) = 0; DV_(i) = 0; W1V_(i) = 0; W2V_(i) = 0; LV_(i) = 0;
 #pragma unroll
       for (int e = 0; e < NB; ++e) { HB_(e, i) = Hb[(size_t)e * np + i]; MB_(e, i) = 0; }
     }
-    if (RES) {
-      for (int ix = tid; ix < JS; ix += NTH) {
-#pragma unroll
-        for (int e = 0; e < NB; ++e) ABL_(e, ix) = Ab[(size_t)e * JS + ix];
-      }
-    }
   }
 
-  // ---- my rows: slots js = w + W*si; bounds from the workspace (scaled by qp_prep_kernel; invalid rows carry
+  // ---- my rows: slots js = w, w + W, ...; bounds from the workspace (scaled by qp_prep_kernel; invalid rows carry
   //      infinite bounds and are inert), initial x = clamp(0, l, u), count finite sides ----
-  RowState st[SW];
   int cnt_local = 0, infeas_l = 0;
-  {
-    const double* __restrict__ Lr = ws + d.off_rows;                       // row array 0: scaled lower bounds
-    const double* __restrict__ Ur = ws + d.off_rows + (size_t)d.rowlen;    // row array 1: scaled upper bounds
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      const int js = w + W * si;
-      RowState& r = st[si];
-      r.l = -INFINITY; r.u = INFINITY; r.tl = r.tu = 1.0; r.zl = r.zu = 0.0; r.v = 0.0; r.dl = r.du = 0.0; r.va = r.vc = r.wc = 0.0;
-      if (js < JT) {
-        double l = Lr[js * 64 + lane], u = Ur[js * 64 + lane];
-        if (l > -INFINITY && u < INFINITY) {
-          if (l > u) infeas_l = 1;
-          if (!(u > l)) {  // equality row: open a tiny interior (documented relaxation)
-            const double eps = 1e-9 * fmax(1.0, fabs(l));
-            l -= eps; u += eps;
-          }
-        }
-        cnt_local += (l > -INFINITY) + (u < INFINITY);
-        r.l = l; r.u = u;
+  for (int js = w; js < JT; js += W) {
+    const int ix = js * 64 + lane;
+    double l = aL[ix], u = aU[ix];
+    if (l > -INFINITY && u < INFINITY) {
+      if (l > u) infeas_l = 1;
+      if (!(u > l)) {  // equality row: open a tiny interior (documented relaxation)
+        const double eps = 1e-9 * fmax(1.0, fabs(l));
+        l -= eps; u += eps; aL[ix] = l; aU[ix] = u;
       }
     }
+    cnt_local += (l > -INFINITY) + (u < INFINITY);
   }
   __syncthreads();   // LDS constants visible, X = 0 written before the owners of the variable slots set it
-#pragma unroll
-  for (int si = 0; si < SW; ++si) {
-    const int js = w + W * si;
-    if (js >= J && js < JT) {
-      const int i = (js - J) * 64 + lane;
+  for (int js = w; js < JT; js += W) {
+    if (js >= J) {
+      const int i = (js - J) * 64 + lane, ix = js * 64 + lane;
       if (i < np) {
+        const double l = aL[ix], u = aU[ix];
         double xi = 0.0;
-        if (st[si].l > -INFINITY && xi < st[si].l) xi = st[si].l;
-        if (st[si].u < INFINITY && xi > st[si].u) xi = st[si].u;
+        if (l > -INFINITY && xi < l) xi = l;
+        if (u < INFINITY && xi > u) xi = u;
         X_(i) = xi;
       }
     }
@@ -336,61 +323,85 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   STAMP_DECL
 
   // ------------------------------------------------------------------------------------------
-  // streaming pass over the k-steps of MY A-row slots (slot js = 16 k-steps = 4 trips).  Per pair of k-steps the body
-  // sees the operands bq[t] (zero beyond the trip's tile count), the first k-step s0 and the owner-layout index rix of
-  // (s0, lane group q); the row value of k-step s0+h belongs to the lane with c == ((s0+h) & 15).
+  // streaming pass over the 16 k-steps (4 trips, 8 pairs) of ONE A-row slot of mine.  The operands of the next pair are
+  // requested before the current pair is handed to the body; the body sees bq[t] (zero beyond the trip's tile count) and the
+  // first k-step s0 of the pair; the row value of k-step s0+h belongs to the lane with c == ((s0+h) & 15).
   // ------------------------------------------------------------------------------------------
-#define SLOT_PASS_BEGIN(si_)                                                                                  \
-    { const int js_ = w + W * (si_);                                                                           \
-      if (js_ < J) {                                                                                            \
-        for (int tr = 4 * js_; tr < 4 * js_ + 4 && tr < ntr; ++tr) {                                            \
-          const int tc = tcs[tr], rbase = aoff[tr];                                                             \
-          _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                       \
-            v2d bq[T];                                                                                          \
-            _Pragma("unroll") for (int t = 0; t < T; ++t) { bq[t] = (v2d){0.0, 0.0}; if (t < tc) bq[t] = opnd(rbase + u * tc + t); } \
-            const int s0 = 4 * tr + 2 * u;                                                                      \
-            const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
-#define SLOT_PASS_END } } } }
+  auto slot_pairs = [&](int js, auto body) AINL {
+    const int p_lo = 8 * js, p_hi = (8 * js + 8 < 2 * ntr) ? 8 * js + 8 : 2 * ntr;
+    v2d cur[T], nxt[T];
+    // the trip's tile count selects a straight-line variant: C loads, T - C zero fills (no per-record branches)
+    auto load_c = [&](auto Cc, int rb, v2d (&o)[T]) AINL {
+      constexpr int C = decltype(Cc)::value;
+#pragma unroll
+      for (int t = 0; t < T; ++t) { if (t < C) o[t] = opnd(rb + t); else o[t] = (v2d){0.0, 0.0}; }
+    };
+    auto load = [&](int pi, v2d (&o)[T]) AINL {
+      const int tr = pi >> 1, tc = tcs[tr], rb = aoff[tr] + (pi & 1) * tc;
+      switch (tc) {
+        case 1: load_c(IC<1>{}, rb, o); break;
+        case 2: if constexpr (T >= 2) load_c(IC<2>{}, rb, o); break;
+        case 3: if constexpr (T >= 3) load_c(IC<3>{}, rb, o); break;
+        case 4: if constexpr (T >= 4) load_c(IC<4>{}, rb, o); break;
+        case 5: if constexpr (T >= 5) load_c(IC<5>{}, rb, o); break;
+        case 6: if constexpr (T >= 6) load_c(IC<6>{}, rb, o); break;
+        case 7: if constexpr (T >= 7) load_c(IC<7>{}, rb, o); break;
+        case 8: if constexpr (T >= 8) load_c(IC<8>{}, rb, o); break;
+        case 9: if constexpr (T >= 9) load_c(IC<9>{}, rb, o); break;
+        case 10: if constexpr (T >= 10) load_c(IC<10>{}, rb, o); break;
+        case 11: if constexpr (T >= 11) load_c(IC<11>{}, rb, o); break;
+        default: if constexpr (T >= 12) load_c(IC<12>{}, rb, o); break;
+      }
+    };
+    if (p_lo < p_hi) load(p_lo, cur);
+    for (int pi = p_lo; pi < p_hi; ++pi) {
+      if (pi + 1 < p_hi) load(pi + 1, nxt);
+      body(cur, 2 * pi);
+#pragma unroll
+      for (int t = 0; t < T; ++t) cur[t] = nxt[t];
+    }
+  };
 
-  // v = A~ z for one LDS vector, my slots; result into dst(si) of the owner lane; variable slots copy z
-  auto rows_Av = [&](int oV, auto dst) AINL {
+  // v = A~ z for one LDS vector, my slots; result into the owner-layout row array `out`; variable slots copy z
+  auto rows_Av = [&](int oV, double* out) AINL {
     double v[T], vb[NBB];
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = slds[oV + 16 * t + c];
 #pragma unroll
     for (int f = 0; f < NBB; ++f) vb[f] = NB ? slds[oV + nc + f] : 0.0;
+    for (int js = w; js < JT; js += W) {
+      if (js < J) {
+        double keep = 0.0;
+        slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
+          const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
 #pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      SLOT_PASS_BEGIN(si)
+          for (int h = 0; h < 2; ++h) {
+            double dsum = 0.0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          double dsum = 0.0;
+            for (int t = 0; t < T; ++t) dsum = fma(bq[t][h], v[t], dsum);
+            dsum = grp16_sum(dsum);
 #pragma unroll
-          for (int t = 0; t < T; ++t) dsum = fma(bq[t][h], v[t], dsum);
-          dsum = grp16_sum(dsum);
-#pragma unroll
-          for (int f = 0; f < NB; ++f) dsum = fma(AB_(f, rix + h), vb[f], dsum);
-          if (c == ((s0 + h) & 15)) dst(si) = dsum;
-        }
-      SLOT_PASS_END
-      const int js = w + W * si;
-      if (js >= J && js < JT) { const int i = (js - J) * 64 + lane; dst(si) = i < n ? slds[oV + i] : 0.0; }
+            for (int f = 0; f < NB; ++f) dsum = fma(AB_(f, rix + h), vb[f], dsum);
+            if (c == ((s0 + h) & 15)) keep = dsum;
+          }
+        });
+        out[js * 64 + lane] = keep;
+      } else { const int i = (js - J) * 64 + lane; out[js * 64 + lane] = i < n ? slds[oV + i] : 0.0; }
     }
   };
-  // A~' y for a per-row value held by the owner lanes (src(si)), my slots -> partial n-vector WP[w].
-  // The owner lane's value is passed to its lane group through the exchange array 0 (wave-private use).
+  // A~' y for a per-row value of the owner lanes (src(ix)), my slots -> partial n-vector WP[w].
+  // The owner lane's value is passed to its lane group through the wave's coefficient stage.
   auto rows_Atw = [&](auto src) AINL {
     double p[T], pbv[NBB];
 #pragma unroll
     for (int t = 0; t < T; ++t) p[t] = 0.0;
 #pragma unroll
     for (int f = 0; f < NBB; ++f) pbv[f] = 0.0;
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      const int js = w + W * si;
-      if (js < J) EX_(0, js * 64 + lane) = src(si);
-      SLOT_PASS_BEGIN(si)
-        const v2d wv = *reinterpret_cast<const v2d*>(&EX_(0, rix));
+    for (int js = w; js < J; js += W) {
+      CWS_(0, lane) = src(js * 64 + lane);
+      slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
+        const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
+        const v2d wv = *reinterpret_cast<const v2d*>(&CWS_(0, q * 16 + (s0 & 15)));
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -398,7 +409,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
 #pragma unroll
           for (int f = 0; f < NB; ++f) pbv[f] = fma(wv[h], AB_(f, rix + h), pbv[f]);
         }
-      SLOT_PASS_END
+      });
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) { const double v = q_sum(p[t]); if (q == 0) slds[oWP + w * np + 16 * t + c] = v; }
@@ -411,11 +422,14 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   };
 
   v4d acc[NTW];          // my tiles of M, then of its Cholesky factor U
-  double Ubb[NBB][NBB];  // Cholesky factor of the border Schur complement (wave-uniform scalars, every wave has them)
+  // Cholesky factor of the border Schur complement: NB x NB scalars in LDS (written and read by the last wave only)
+#define UBB_(e, f) slds[oUbb + (e) * NBB + (f)]
 
-  // acc = H~ (my tiles) and, from the same registers, my share of H~ z -> partial n-vector WP[1][w]; then HX = sum of the
-  // partials + border columns.  (Tile (I,J), I < J, contributes H_IJ z_J to rows I and H_IJ' z_I to rows J.)
-  auto acc_init_hx = [&](int oZ) AINL {
+  // HX = H~ z from my tiles of H~ (partial n-vector per wave, then the sum + border columns).  KEEP: the accumulators hold the
+  // resident factor and stay untouched (refinement); else acc = H~ (my tiles) comes out of the same loads.
+  // (Tile (I,J), I < J, contributes H_IJ z_J to rows I and H_IJ' z_I to rows J.)
+  auto hx_tiles = [&](int oZ, auto keep_tag) AINL {
+    constexpr bool KEEP = decltype(keep_tag)::value;
     for (int i = lane; i < np; i += 64) slds[oPB + w * np + i] = 0.0;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
@@ -424,26 +438,22 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
         const double* hp = Hw + ((size_t)(tI[t] * T + tJ[t]) * 4) * 64 + lane;
 #pragma unroll
         for (int p = 0; p < 4; ++p) h[p] = hp[p * 64];
-      }
-      acc[t] = h;
-    }
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-      if (tJ[t] < T) {
         const int I = tI[t], Jt = tJ[t];
         const double zc = slds[oZ + 16 * Jt + c];
         double colsum = 0.0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-          const double rs = grp16_sum(acc[t][p] * zc);                       // row 16I + q + 4p of H_IJ z_J
+          const double rs = grp16_sum(h[p] * zc);                            // row 16I + q + 4p of H_IJ z_J
           if (c == 0) slds[oPB + w * np + 16 * I + q + 4 * p] += rs;
-          colsum = fma(acc[t][p], slds[oZ + 16 * I + q + 4 * p], colsum);
+          colsum = fma(h[p], slds[oZ + 16 * I + q + 4 * p], colsum);
         }
         if (I != Jt) {
           colsum = q_sum(colsum);                                            // column 16J + c of H_IJ' z_I
           if (q == 0) slds[oPB + w * np + 16 * Jt + c] += colsum;
         }
       }
+      if (!KEEP) acc[t] = h;
+    }
     __syncthreads();
     for (int i = tid; i < np; i += NTH) {
       double hx = 0.0;
@@ -465,34 +475,46 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     }
     __syncthreads();
   };
+  auto acc_init_hx = [&](int oZ) AINL { hx_tiles(oZ, TagInit{}); };
+  auto hx_keep = [&](int oZ) AINL { hx_tiles(oZ, TagKeep{}); };
+  auto acc_init = [&]() AINL {   // acc = H~ (my tiles) alone
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      v4d h = {0.0, 0.0, 0.0, 0.0};
+      if (tJ[t] < T) {
+        const double* hp = Hw + ((size_t)(tI[t] * T + tJ[t]) * 4) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) h[p] = hp[p * 64];
+      }
+      acc[t] = h;
+    }
+  };
 
   // ---- v = G x ----
-  rows_Av(VEC(V_X), [&](int si) AINL -> double& { return st[si].v; });
+  rows_Av(VEC(V_X), aV);
   // ---- initial slacks / multipliers in the equilibrated problem: t = max(resid, T0), z = Z0 ----
   const double T0 = 10.0, Z0 = 100.0;
-#pragma unroll
-  for (int si = 0; si < SW; ++si) {
-    RowState& r = st[si];
-    const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
-    r.tl = hl ? fmax(r.v - r.l, T0) : 1.0;
-    r.tu = hu ? fmax(r.u - r.v, T0) : 1.0;
-    r.zl = hl ? Z0 : 0.0;
-    r.zu = hu ? Z0 : 0.0;
+  for (int js = w; js < JT; js += W) {
+    const int ix = js * 64 + lane;
+    const double l = aL[ix], u = aU[ix], v = aV[ix];
+    const bool hl = l > -INFINITY, hu = u < INFINITY;
+    aTL[ix] = hl ? fmax(v - l, T0) : 1.0;
+    aTU[ix] = hu ? fmax(u - v, T0) : 1.0;
+    aZL[ix] = hl ? Z0 : 0.0;
+    aZU[ix] = hu ? Z0 : 0.0;
   }
   // bound multipliers absorb the initial dual residual r = Hx + g - A'(zl - zu)
   {
     acc_init_hx(VEC(V_X));
-    rows_Atw([&](int si) AINL { return st[si].zl - st[si].zu; });
+    rows_Atw([&](int ix) AINL { return aZL[ix] - aZU[ix]; });
     __syncthreads();
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      const int js = w + W * si;
-      if (js >= J && js < JT) {
-        const int i = (js - J) * 64 + lane;
+    for (int js = w; js < JT; js += W) {
+      if (js >= J) {
+        const int i = (js - J) * 64 + lane, ix = js * 64 + lane;
         if (i < n) {
           const double r = HX_(i) + G_(i) - part(i);
-          if (st[si].l > -INFINITY) st[si].zl = fmax(r, 0.0) + Z0;
-          if (st[si].u < INFINITY) st[si].zu = fmax(-r, 0.0) + Z0;
+          if (aL[ix] > -INFINITY) aZL[ix] = fmax(r, 0.0) + Z0;
+          if (aU[ix] < INFINITY) aZU[ix] = fmax(-r, 0.0) + Z0;
         }
       }
     }
@@ -502,57 +524,29 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   // fall-back iterate (best one that met tol_loose): x in the workspace, multipliers per owner lane in the workspace
   double saved_merit = INFINITY, best_res = INFINITY;
   int have_saved = 0, stall = 0;
-  double* __restrict__ XS = ws + d.off_save;            // np
-  double* __restrict__ LAMS = ws + d.off_save + np;     // rowlen (owner layout; written and read by the owner lanes only)
+  double* XS = ws + d.off_save;            // np
+  double* LAMS = ws + d.off_save + np;     // rowlen (owner layout; written and read by the owner lanes only)
 
-  // residuals and barrier weights of my rows: everything pass 1 needs goes to the exchange arrays 0..3 (A rows) or
-  // the variable-row vectors; returns the complementarity sum and the relative primal residual of my rows
-  auto row_weights = [&](double& s_gap, double& m_rp) AINL {
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      const int js = w + W * si;
-      RowState& r = st[si];
-      const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
-      const double rpl = hl ? r.v - r.l - r.tl : 0.0, rpu = hu ? r.u - r.v - r.tu : 0.0;
-      r.dl = hl ? r.zl / r.tl : 0.0; r.du = hu ? r.zu / r.tu : 0.0;
-      const double D = r.dl + r.du;
-      const double W1 = -r.dl * rpl + r.du * rpu;                           // affine rhs weight
-      const double W2 = (hl ? 1.0 / r.tl : 0.0) - (hu ? 1.0 / r.tu : 0.0);  // centering weight (times sigma*mu)
-      const double W3 = (hl ? r.zl : 0.0) - (hu ? r.zu : 0.0);              // current multiplier (for the dual residual)
-      if (js < J) { const int ix = js * 64 + lane; EX_(0, ix) = D; EX_(1, ix) = W1; EX_(2, ix) = W2; EX_(3, ix) = W3; }
-      else if (js < JT) { const int i = (js - J) * 64 + lane; if (i < np) { DV_(i) = D; W1V_(i) = W1; W2V_(i) = W2; LV_(i) = W3; } }
-      s_gap += (hl ? r.tl * r.zl : 0.0) + (hu ? r.tu * r.zu : 0.0);
-      const double sc = fmax(1.0, fabs(r.v));
-      if (hl) m_rp = fmax(m_rp, fabs(rpl) / fmax(sc, fabs(r.l)));
-      if (hu) m_rp = fmax(m_rp, fabs(rpu) / fmax(sc, fabs(r.u)));
-    }
+  auto ld_row = [&](int ix) AINL -> Row { Row r; r.l = aL[ix]; r.u = aU[ix]; r.tl = aTL[ix]; r.tu = aTU[ix]; r.zl = aZL[ix]; r.zu = aZU[ix]; r.v = aV[ix]; return r; };
+  // residuals and barrier weights of one row: what pass 1 needs goes to the row arrays D, W1, W2, W3 (A rows) or the
+  // variable-row vectors; accumulates the complementarity sum and the relative primal residual
+  auto row_weights = [&](int js, const Row& r, double& s_gap, double& m_rp) AINL {
+    const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
+    const double rpl = hl ? r.v - r.l - r.tl : 0.0, rpu = hu ? r.u - r.v - r.tu : 0.0;
+    const double dl = hl ? r.zl / r.tl : 0.0, du = hu ? r.zu / r.tu : 0.0;
+    const double D = dl + du;
+    const double W1 = -dl * rpl + du * rpu;                               // affine rhs weight
+    const double W2 = (hl ? 1.0 / r.tl : 0.0) - (hu ? 1.0 / r.tu : 0.0);  // centering weight (times sigma*mu)
+    const double W3 = (hl ? r.zl : 0.0) - (hu ? r.zu : 0.0);              // current multiplier (for the dual residual)
+    if (js < J) { const int ix = js * 64 + lane; aD[ix] = D; aW1[ix] = W1; aW2[ix] = W2; aW3[ix] = W3; }
+    else { const int i = (js - J) * 64 + lane; if (i < np) { DV_(i) = D; W1V_(i) = W1; W2V_(i) = W2; LV_(i) = W3; } }
+    s_gap += (hl ? r.tl * r.zl : 0.0) + (hu ? r.tu * r.zu : 0.0);
+    const double sc = fmax(1.0, fabs(r.v));
+    if (hl) m_rp = fmax(m_rp, fabs(rpl) / fmax(sc, fabs(r.l)));
+    if (hu) m_rp = fmax(m_rp, fabs(rpu) / fmax(sc, fabs(r.u)));
   };
   double gap = 0.0, rp_rel = 0.0;   // carried across iterations (produced by the update sweep)
 
-  // right-hand-side tile row K of `ns` contiguous LDS vectors starting at vo: B-operand form, column e = vector e
-  auto rhs_load = [&](int K, int vo, int ns) AINL -> v4d {
-    v4d r = {0.0, 0.0, 0.0, 0.0};
-    if (c < ns) {
-      const int o = vo + c * np + 16 * K + q;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) r[p] = slds[o + 4 * p];
-    }
-    return r;
-  };
-  auto rhs_store = [&](int K, int vo, int ns, const v4d& r) AINL {
-    if (c < ns) {
-      const int o = vo + c * np + 16 * K + q;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) slds[o + 4 * p] = r[p];
-    }
-  };
-  auto rhs_sub = [&](int K, int vo, int ns, const v4d& r) AINL {   // the only writer of row K at this step
-    if (c < ns) {
-      const int o = vo + c * np + 16 * K + q;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) slds[o + 4 * p] -= r[p];
-    }
-  };
   auto tile_store17 = [&](int o, const v4d& Xt) AINL {
 #pragma unroll
     for (int p = 0; p < 4; ++p) slds[o + (q + 4 * p) * 17 + c] = Xt[p];
@@ -580,68 +574,94 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     return Z;
   };
 
-  // forward solve U'y = b for `ns` LDS vectors with the resident factor, in place.  One barrier per block step: every
-  // wave that owns a tile of block row K forms y_K = U_KK^-T b_K itself; the owner of the diagonal tile writes y_K back
-  // one step later (nobody reads row K by then).
-  auto fwd_solve = [&](int vo, int ns) AINL {
-    v4d ydef = {0.0, 0.0, 0.0, 0.0}; int kdef = -1;
+  // ---- triangular solves: ONE wavefront per right-hand side, on the VALU (as vec_forward / vec_backward of qp_solver.hip) ----
+  // After a factorisation every wave leaves its tiles of U in the workspace as register images (72 KB at T = 8: they stay in L2);
+  // the solving wave streams them from there, U_KK^-T comes from LDS.  A solve is then a few thousand cycles of one wave and no
+  // workgroup barrier per block step (round 2 rode the right-hand sides through the factorisation and the solves as 16-wide tile
+  // columns on the matrix cores with a barrier per block step: ~35-60 k cycles per solve).  Several right-hand sides are solved by
+  // several waves side by side.  Vector layouts: "by column" lane (c, .) holds v[c]; "by row" reg p of lane (., q) holds v[q + 4p].
+  double* Ug = ws + d.off_U;
+  auto store_factor = [&]() AINL {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+      if (tJ[t] < T) {
+        double* up = Ug + (size_t)(w + W * t) * 256 + lane;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) up[p * 64] = acc[t][p];
+      }
+  };
+  auto utile = [&](int I, int Jt) AINL -> v4d {
+    const double* up = Ug + (size_t)(Jt * (Jt + 1) / 2 + I) * 256 + lane;
+    v4d z;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) z[p] = up[p * 64];
+    return z;
+  };
+  // U'y = b in place on the LDS vector at oV (core part), right-looking: y_K = U_KK^-T b_K (+ one step of refinement against U_KK),
+  // then b_J -= U_KJ' y_K for J > K.  Called by one wave.
+  auto vec_fwd = [&](int oV) AINL {
 #pragma unroll
     for (int K = 0; K < T; ++K) {
-      bool need = false;
+      const double tk = slds[oV + 16 * K + c];
+      const v4d Yt = tile_load17(oYL + K * 272);                                      // U_KK^-T
+      const v4d Ukk = utile(K, K);
+      double y[4];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) need = need || (tI[t] == K && tJ[t] < T);
-      if (kdef >= 0) { rhs_store(kdef, vo, ns, ydef); kdef = -1; }
-      if (need) {
-        const v4d yk = mfma4_new(tile_load17_t(oYL + K * 272), rhs_load(K, vo, ns));     // U_KK^-T b_K
+      for (int p = 0; p < 4; ++p) y[p] = grp16_sum(Yt[p] * tk);                       // y_K[q+4p] = sum_c Y[q+4p][c] t[c]
+      {
+        double r = 0.0;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          if (tI[t] == K && tJ[t] == K) { ydef = yk; kdef = K; }
-          if (tI[t] == K && tJ[t] > K && tJ[t] < T) rhs_sub(tJ[t], vo, ns, mfma4_new(acc[t], yk));   // b_J -= U_KJ' y_K
-        }
+        for (int p = 0; p < 4; ++p) r = fma(Ukk[p], y[p], r);
+        r = tk - q_sum(r);                                                             // t - U_KK' y  (by column)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) y[p] += grp16_sum(Yt[p] * r);
       }
-      __syncthreads();
+      if (c == 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) slds[oV + 16 * K + q + 4 * p] = y[p];
+      }
+#pragma unroll
+      for (int Jt = K + 1; Jt < T; ++Jt) {
+        const v4d Ukj = utile(K, Jt);
+        double sj = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sj = fma(Ukj[p], y[p], sj);                        // this lane group's rows of (U_KJ' y_K)[c]
+        sj = q_sum(sj);
+        if (q == 0) slds[oV + 16 * Jt + c] -= sj;
+      }
     }
-    if (kdef >= 0) rhs_store(kdef, vo, ns, ydef);
-    __syncthreads();
   };
-  // backward solve U x = y in place, one barrier per block step: every wave that owns a tile of block column K forms
-  // x_K = U_KK^-1 y_K itself (matrix cores), turns it into the row-indexed form through its private LDS scratch, and
-  // applies U_IK x_K on the VALU (no tile transposes)
-  auto bwd_solve = [&](int vo, int ns) AINL {
-    v4d xdef = {0.0, 0.0, 0.0, 0.0}; int kdef = -1;
+  // U x = y in place: x_K = U_KK^-1 (y_K - sum_{J>K} U_KJ x_J) (+ one step of refinement).  Called by one wave.
+  auto vec_bwd = [&](int oV) AINL {
+    double x[T];
 #pragma unroll
     for (int K = T - 1; K >= 0; --K) {
-      bool need = false;
+      const v4d Yt = tile_load17(oYL + K * 272);
+      const v4d Ukk = utile(K, K);
+      double sp[4] = {0.0, 0.0, 0.0, 0.0}, wv[4];
 #pragma unroll
-      for (int t = 0; t < NTW; ++t) need = need || (tJ[t] == K);
-      if (kdef >= 0) { rhs_store(kdef, vo, ns, xdef); kdef = -1; }
-      if (need) {
-        const v4d xk = mfma4_new(tile_load17(oYL + K * 272), rhs_load(K, vo, ns));       // (U_KK^-T)' y_K = U_KK^-1 y_K
-        if (c < ns) {
+      for (int Jt = K + 1; Jt < T; ++Jt) {
+        const v4d Ukj = utile(K, Jt);
 #pragma unroll
-          for (int p = 0; p < 4; ++p) slds[oScr + w * 96 + c * 16 + q + 4 * p] = xk[p];   // scratch[e][row]
-        }
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          if (tJ[t] == K && tI[t] == K) { xdef = xk; kdef = K; }
-          if (tJ[t] == K && tI[t] < K) {
-            for (int e = 0; e < ns; ++e) {
-              const double xc = slds[oScr + w * 96 + e * 16 + c];
-#pragma unroll
-              for (int p = 0; p < 4; ++p) {
-                const double sm = grp16_sum(acc[t][p] * xc);                // row q+4p of U_IK times x_K
-                if (c == 0) slds[vo + e * np + 16 * tI[t] + q + 4 * p] -= sm;
-              }
-            }
-          }
-        }
+        for (int p = 0; p < 4; ++p) sp[p] = fma(Ukj[p], x[Jt], sp[p]);                 // this lane's column of (U_KJ x_J)[q+4p]
       }
-      __syncthreads();
+      double s2 = 0.0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        wv[p] = slds[oV + 16 * K + q + 4 * p] - (K < T - 1 ? grp16_sum(sp[p]) : 0.0);
+        s2 = fma(Yt[p], wv[p], s2);
+      }
+      x[K] = q_sum(s2);                                                                // (U_KK^-T)' w
+      {
+        double dcor = 0.0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) dcor = fma(Yt[p], wv[p] - grp16_sum(Ukk[p] * x[K]), dcor);
+        x[K] += q_sum(dcor);
+      }
+      if (q == 0) slds[oV + 16 * K + c] = x[K];
     }
-    if (kdef >= 0) rhs_store(kdef, vo, ns, xdef);
-    __syncthreads();
   };
-  // border part of a solve (the last wave writes; every wave holds Ubb): R holds y_c = U^-T b_c (core) and b_b
+  // border part of a solve (the last wave does it; the factor of the border block is in LDS): R holds y_c = U^-T b_c (core) and b_b
   // (border); leaves the border solution in R[nc+e] and y_c - sum_e u_e x_e in the core.  Caller syncs.
   auto border_solve = [&](int oR) AINL {
     if (NB > 0 && w == W - 1) {
@@ -652,15 +672,15 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
         for (int i = lane; i < nc; i += 64) dsum = fma(MB_(e, i), slds[oR + i], dsum);
         double tt = slds[oR + nc + e] - wave_sum(dsum);
 #pragma unroll
-        for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * yb[g2];
-        yb[e] = tt / Ubb[e][e];
+        for (int g2 = 0; g2 < e; ++g2) tt -= UBB_(g2, e) * yb[g2];
+        yb[e] = tt / UBB_(e, e);
       }
 #pragma unroll
       for (int e = NB - 1; e >= 0; --e) {
         double tt = yb[e];
 #pragma unroll
-        for (int f = e + 1; f < NB; ++f) tt -= Ubb[e][f] * xb[f];
-        xb[e] = tt / Ubb[e][e];
+        for (int f = e + 1; f < NB; ++f) tt -= UBB_(e, f) * xb[f];
+        xb[e] = tt / UBB_(e, e);
       }
       for (int i = lane; i < nc; i += 64) {
         double r = slds[oR + i];
@@ -676,9 +696,9 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   };
 
   // M = (acc from pass 1) + diag(DV) on the variable rows, border columns = H~ border + A'DA border (MB); blocked
-  // right-looking Cholesky over the distributed tiles with the right-hand sides R1, R2 (and the NB border columns)
-  // riding along, then the border Schur complement and the backward solve for R1, R2.  Returns 1 on a non-finite pivot.
-  auto factor_solve2 = [&]() AINL -> int {
+  // right-looking Cholesky over the distributed tiles, then (with_rhs) the solves for R1, R2 in place: forward sweeps of R1, R2 and
+  // the NB border columns side by side (one wave each), the border Schur complement, backward sweeps.  Returns 1 on a non-finite pivot.
+  auto factor_solve2 = [&](bool with_rhs) AINL -> int {
     double dmax_l = 0;
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
@@ -706,9 +726,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     red_next();
     const double floor_abs = 1e-30 * dmax;
     STAMP(5);
-    const int vo = VEC(V_R1);          // right-hand-side columns: R1, R2, MB[0..NB-1] (contiguous vectors)
     int fbad = 0;
-    v4d ydef = {0.0, 0.0, 0.0, 0.0}; int kdef = -1;
 #pragma unroll
     for (int K = 0; K < T; ++K) {
       // A: the diagonal tile (its owner arrives here straight from its trailing update of step K-1)
@@ -723,18 +741,16 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
           img_store(oUK, acc[t]);                        // U_KK itself: the block row is refined against it
         }
       __syncthreads();
-      // B: block row K: U_KJ = U_KK^-T M_KJ -> panel images; y_K = U_KK^-T b_K formed by every wave of the row; b_J -= U_KJ' y_K
+      // B: block row K: U_KJ = U_KK^-T M_KJ -> panel images
       {
         bool need = false;
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) need = need || (tI[t] == K && tJ[t] < T);
+        for (int t = 0; t < NTW; ++t) need = need || (tI[t] == K && tJ[t] > K && tJ[t] < T);
         if (need) {
           const v4d Wk = tile_load17_t(oYL + K * 272);             // U_KK^-1 as the A operand acts as U_KK^-T
           const v4d Ukk = img_load(oUK);
-          const v4d yk = mfma4_new(Wk, rhs_load(K, vo, NS));
 #pragma unroll
           for (int t = 0; t < NTW; ++t) {
-            if (tI[t] == K && tJ[t] == K) { ydef = yk; kdef = K; }
             if (tI[t] == K && tJ[t] > K && tJ[t] < T) {
               // U_KJ = U_KK^-T M_KJ through the explicit inverse + one step of refinement against U_KK (see FactorStep in
               // qp_solver.hip: the unrefined row carries a backward error of cond(U_KK) eps)
@@ -744,99 +760,123 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
 #pragma unroll
               for (int p = 0; p < 4; ++p) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wk[p], Rr[p], acc[t], 0, 0, 0);
               img_store(oPB + tJ[t] * 256, acc[t]);
-              rhs_sub(tJ[t], vo, NS, mfma4_new(acc[t], yk));
             }
           }
         }
       }
       __syncthreads();
-      // C: trailing update M_IJ -= U_KI' U_KJ; the owner of the diagonal tile writes y_K back (row K is final now)
-      if (kdef >= 0) { rhs_store(kdef, vo, NS, ydef); kdef = -1; }
+      // C: trailing update M_IJ -= U_KI' U_KJ
 #pragma unroll
       for (int t = 0; t < NTW; ++t)
         if (tI[t] > K && tI[t] < T) mfma4_sub(img_load(oPB + tI[t] * 256), img_load(oPB + tJ[t] * 256), acc[t]);
     }
+    store_factor();
     red_put(0, (double)fbad);
-    __syncthreads();
+    __syncthreads();                                       // factor tiles in the workspace, U_KK^-T tiles in LDS: visible to the solving waves
     fbad = red_max(0) > 0;
     red_next();
     STAMP(6);
-    if (NB > 0) {   // bordered factor: u_e = U^-T m_e came out of the forward sweep; S = M_bb - u'u is factorised as scalars
-      double S[NBB][NBB];
-#pragma unroll
-      for (int e = 0; e < NB; ++e)
-#pragma unroll
-        for (int f = e; f < NB; ++f) {
-          double dsum = 0.0;
-          for (int i = lane; i < nc; i += 64) dsum = fma(MB_(e, i), MB_(f, i), dsum);
-          S[e][f] = MB_(e, nc + f) - wave_sum(dsum);
-        }
-#pragma unroll
-      for (int e = 0; e < NB; ++e) {
-        double dd = S[e][e];
-#pragma unroll
-        for (int g2 = 0; g2 < e; ++g2) dd -= Ubb[g2][e] * Ubb[g2][e];
-        if (!(dd > floor_abs)) { if (!(fabs(dd) < INFINITY)) fbad = 1; dd = floor_abs; }
-        Ubb[e][e] = sqrt(dd);
-#pragma unroll
-        for (int f = e + 1; f < NB; ++f) {
-          double tt = S[e][f];
-#pragma unroll
-          for (int g2 = 0; g2 < e; ++g2) tt -= Ubb[g2][e] * Ubb[g2][f];
-          Ubb[e][f] = tt / Ubb[e][e];
-        }
-      }
-    }
     if (fbad) return 1;
-    if (NB > 0) {
-      border_solve(VEC(V_R1)); border_solve(VEC(V_R2));
+    // forward sweeps, one wave per right-hand side (R1, R2 and the NB border columns are contiguous LDS vectors; right-hand side e
+    // goes to wave W-1 - e mod W: R1 to the last wave, R2 to the one before)
+    for (int e = W - 1 - w; e < NS; e += W) if (e >= 2 || with_rhs) vec_fwd(VEC(V_R1 + e));
+    if constexpr (NB > 0) {
+      __syncthreads();
+      // bordered factor: u_e = U^-T m_e; S = M_bb - u'u is factorised as scalars by the last wave, which also owns border_solve
+      int fb2 = 0;
+      if (w == W - 1) {
+        double S[NBB][NBB], Ub[NBB][NBB];
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+#pragma unroll
+          for (int f = e; f < NB; ++f) {
+            double dsum = 0.0;
+            for (int i = lane; i < nc; i += 64) dsum = fma(MB_(e, i), MB_(f, i), dsum);
+            S[e][f] = MB_(e, nc + f) - wave_sum(dsum);
+          }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+          double dd = S[e][e];
+#pragma unroll
+          for (int g2 = 0; g2 < e; ++g2) dd -= Ub[g2][e] * Ub[g2][e];
+          if (!(dd > floor_abs)) { if (!(fabs(dd) < INFINITY)) fb2 = 1; dd = floor_abs; }
+          Ub[e][e] = sqrt(dd);
+#pragma unroll
+          for (int f = e + 1; f < NB; ++f) {
+            double tt = S[e][f];
+#pragma unroll
+            for (int g2 = 0; g2 < e; ++g2) tt -= Ub[g2][e] * Ub[g2][f];
+            Ub[e][f] = tt / Ub[e][e];
+          }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int e = 0; e < NB; ++e)
+#pragma unroll
+            for (int f = e; f < NB; ++f) UBB_(e, f) = Ub[e][f];
+        }
+        if (with_rhs) { border_solve(VEC(V_R1)); border_solve(VEC(V_R2)); }
+      }
+      red_put(0, (double)fb2);
+      __syncthreads();
+      fbad = red_max(0) > 0;
+      red_next();
+      if (fbad) return 1;
+    }
+    if (with_rhs) {
+      if (NB == 0) __syncthreads();                       // (with a border the barrier above already separates the sweeps)
+      if (w >= W - 2) vec_bwd(VEC(V_R1 + (W - 1 - w)));
       __syncthreads();
     }
-    bwd_solve(vo, 2);
     return 0;
   };
-  // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place)
+  // one more solve with the resident factor: V <- M^-1 V (LDS n-vector, in place), by the last wave
   auto solve1 = [&](int oV) AINL {
-    fwd_solve(oV, 1);
-    if (NB > 0) { border_solve(oV); __syncthreads(); }
-    bwd_solve(oV, 1);
+    if (w == W - 1) {
+      vec_fwd(oV);
+      if (NB > 0) border_solve(oV);
+      vec_bwd(oV);
+    }
+    __syncthreads();
   };
 
   // pass 1: acc += A~' D A~ on the matrix cores (my tiles); A~'w1..w3 and the border products for my column tiles on
-  // the VALU beside them.  Per-row weights from the exchange arrays 0..3.  Writes P1..P3 and MB (border column / block
+  // the VALU beside them.  Per-row weights from the row arrays D, W1, W2, W3.  Writes P1..P3 and MB (border column / block
   // of A'DA) directly (one owner per entry).
   auto pass_syrk = [&]() AINL {
-    double p1[CW], p2[CW], p3[CW], pb[NBB][CW], sbb[NBB][NBB], pwb[3][NBB];
+    double p1[CW], p2[CW], p3[CW], pb[NBB][CW];
 #pragma unroll
     for (int ci = 0; ci < CW; ++ci) {
       p1[ci] = p2[ci] = p3[ci] = 0.0;
 #pragma unroll
       for (int e = 0; e < NBB; ++e) pb[e][ci] = 0.0;
     }
+    if constexpr (NB > 0) {
+      // border block of A'DA and border entries of A'w1..w3: sums over ALL rows of products of per-row numbers only -- a sweep over
+      // my slots (owner lanes), one wave reduction per sum, partials into the per-wave scratch (summed behind the pass's barriers)
+      constexpr int NSUM = NB * (NB + 1) / 2 + 3 * NB;
+      static_assert(NSUM <= 96, "per-wave scratch");
+      double sm[NSUM];
 #pragma unroll
-    for (int e = 0; e < NBB; ++e) {
+      for (int k_ = 0; k_ < NSUM; ++k_) sm[k_] = 0.0;
+      for (int js = w; js < J; js += W) {
+        const int ix = js * 64 + lane;
+        const double dd = aD[ix], w1 = aW1[ix], w2 = aW2[ix], w3 = aW3[ix];
+        double ab[NB];
 #pragma unroll
-      for (int f = 0; f < NBB; ++f) sbb[e][f] = 0.0;
-      pwb[0][e] = pwb[1][e] = pwb[2][e] = 0.0;
+        for (int e = 0; e < NB; ++e) ab[e] = AB_(e, ix);
+        int k_ = 0;
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+#pragma unroll
+          for (int f = e; f < NB; ++f) { sm[k_] = fma(dd * ab[e], ab[f], sm[k_]); ++k_; }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) { sm[k_] = fma(w1, ab[e], sm[k_]); ++k_; sm[k_] = fma(w2, ab[e], sm[k_]); ++k_; sm[k_] = fma(w3, ab[e], sm[k_]); ++k_; }
+      }
+#pragma unroll
+      for (int k_ = 0; k_ < NSUM; ++k_) { const double t_ = wave_sum(sm[k_]); if (lane == 0) slds[oScr + w * 96 + k_] = t_; }
     }
-    // software pipeline over the pairs of k-steps: the operands and per-row weights of pair pi+1 are requested before
-    // the matrix-core work of pair pi is issued
     struct PairOps { v2d bi[NTW], bj[NTW], bc[CW], dd, w1, w2, w3, ab[NBB]; int tc; };
-    auto load_pair = [&](int pi, PairOps& o) AINL {
-      const int tr = pi >> 1, u = pi & 1;
-      const int tc = tcs[tr], rb = aoff[tr] + u * tc;
-      const int s0 = 4 * tr + 2 * u;
-      const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
-      o.tc = tc;
-      o.dd = *reinterpret_cast<const v2d*>(&EX_(0, rix)); o.w1 = *reinterpret_cast<const v2d*>(&EX_(1, rix));
-      o.w2 = *reinterpret_cast<const v2d*>(&EX_(2, rix)); o.w3 = *reinterpret_cast<const v2d*>(&EX_(3, rix));
-#pragma unroll
-      for (int e = 0; e < NB; ++e) o.ab[e] = AB2_(e, rix);
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) if (tJ[t] < tc) { o.bi[t] = opnd(rb + tI[t]); o.bj[t] = opnd(rb + tJ[t]); }
-#pragma unroll
-      for (int ci = 0; ci < CW; ++ci) if (w + W * ci < tc) o.bc[ci] = opnd(rb + w + W * ci);
-    };
     auto do_pair = [&](const PairOps& o) AINL {
       const int tc = o.tc;
 #pragma unroll
@@ -857,19 +897,119 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
             for (int e = 0; e < NB; ++e) pb[e][ci] = fma(o.dd[h] * o.ab[e][h], bch, pb[e][ci]);
           }
         }
-      if (NB > 0 && w == W - 1) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int e = 0; e < NB; ++e) {
-            const double dab = o.dd[h] * o.ab[e][h];
-#pragma unroll
-            for (int f = e; f < NB; ++f) sbb[e][f] = fma(dab, o.ab[f][h], sbb[e][f]);
-            pwb[0][e] = fma(o.w1[h], o.ab[e][h], pwb[0][e]); pwb[1][e] = fma(o.w2[h], o.ab[e][h], pwb[1][e]); pwb[2][e] = fma(o.w3[h], o.ab[e][h], pwb[2][e]);
-          }
-      }
     };
-    {
+    if constexpr (RING) {
+      // Workgroup-shared operand ring: chunk = one trip (2 pairs x tc records).  Per trip: every wave waits for its own
+      // outstanding DMAs / stage loads, the stage of the trip's row weights is committed, ONE barrier (chunk `tr` has landed
+      // for everybody, everybody is done reading chunk `tr-1`), then the DMAs of trip tr+1 are issued into the other chunk
+      // and fly during the matrix-core work of trip tr.
+      auto issue = [&](int tr, int chunk) AINL {
+        const int nrec = 2 * tcs[tr];
+        const char* g0 = reinterpret_cast<const char*>(Awg + (size_t)aoff[tr] * 128);
+        for (int r = w; r < nrec; r += W)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (size_t)r * 1024 + lane * 16),
+                                           (__attribute__((address_space(3))) void*)(&slds[oRing + (chunk * 2 * T + r) * 128]), 16, 0, 0);
+      };
+      // stage of the trip's 16 rows x (4 weights + NB border columns): lane a*16 + e of the staging wave(s) holds array a, entry e
+      // (e = lane group * 4 + k-step of the trip)
+      auto stage_load = [&](int tr, double (&reg)[2]) AINL {
+        const int s = 4 * tr, js = s >> 4, e = lane & 15;
+        const int ix = js * 64 + (e >> 2) * 16 + (s & 15) + (e & 3);
+        const int a = lane >> 4;   // wave W-1: arrays 0..3 (D, W1, W2, W3); wave W-2: border columns 0..3
+        reg[0] = reg[1] = 0.0;
+        if (w == W - 1) reg[0] = (a == 0 ? aD : (a == 1 ? aW1 : (a == 2 ? aW2 : aW3)))[ix];
+        if (NB > 0 && w == W - 2 && a < NB) reg[1] = Abg[(size_t)a * JS + ix];
+      };
+      auto stage_commit = [&](int buf, const double (&reg)[2]) AINL {
+        if (w == W - 1) slds[oC1 + buf * C1S + lane] = reg[0];
+        if (NB > 0 && w == W - 2 && (lane >> 4) < NB) slds[oC1 + buf * C1S + 64 + lane] = reg[1];
+      };
+      double sreg[2] = {0.0, 0.0};
+      if (ntr > 0) { issue(0, 0); stage_load(0, sreg); }
+      for (int tr = 0; tr < ntr; ++tr) {
+        const int ch = tr & 1;
+#if QP_STAMPS
+        const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_commit(ch, sreg);
+        __syncthreads();
+#if QP_STAMPS
+        st_acc[15] += __builtin_amdgcn_s_memtime() - tw0_;   // diagnostic build: share of pass 1 spent in the per-trip wait + barrier
+#endif
+        if (tr + 1 < ntr) { issue(tr + 1, ch ^ 1); stage_load(tr + 1, sreg); }
+        asm volatile("" ::: "memory");
+        const int tc = tcs[tr];
+        // My active tiles of this trip are a PREFIX of my tile list (tiles are dealt in column-major order, so tJ[t] grows with t):
+        // their count selects a straight-line body -- every LDS read of the pair issued up front, then the multiplies, then the
+        // matrix-core instructions back to back, no per-tile branches and waits.
+        int nact = 0;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) nact += (tJ[t] < tc) ? 1 : 0;
+        auto pair_k = [&](auto Kc, int u) AINL {
+          constexpr int K = decltype(Kc)::value;
+          constexpr int KK = K > 0 ? K : 1;
+          const int cq = oC1 + ch * C1S + q * 4 + 2 * u;
+          const int rb = oRing + (ch * 2 * T + u * tc) * 128 + lane * 2;
+          v2d bi[KK], bj[KK], bc[CW], ab[NBB];
+          const v2d dd = *reinterpret_cast<const v2d*>(&slds[cq]), w1 = *reinterpret_cast<const v2d*>(&slds[cq + 16]);
+          const v2d w2 = *reinterpret_cast<const v2d*>(&slds[cq + 32]), w3 = *reinterpret_cast<const v2d*>(&slds[cq + 48]);
+#pragma unroll
+          for (int t = 0; t < K; ++t) { bi[t] = *reinterpret_cast<const v2d*>(&slds[rb + tI[t] * 128]); bj[t] = *reinterpret_cast<const v2d*>(&slds[rb + tJ[t] * 128]); }
+#pragma unroll
+          for (int ci = 0; ci < CW; ++ci) { const int ct = w + W * ci; bc[ci] = *reinterpret_cast<const v2d*>(&slds[rb + (ct < tc ? ct : 0) * 128]); }
+#pragma unroll
+          for (int e = 0; e < NB; ++e) ab[e] = *reinterpret_cast<const v2d*>(&slds[cq + 64 + 16 * e]);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < K; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[h] * bi[t][h], bj[t][h], acc[t], 0, 0, 0);
+          // VALU side products for my column tiles
+#pragma unroll
+          for (int ci = 0; ci < CW; ++ci) {
+            const double act = (w + W * ci < tc) ? 1.0 : 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const double bch = act * bc[ci][h];
+              p1[ci] = fma(w1[h], bch, p1[ci]); p2[ci] = fma(w2[h], bch, p2[ci]); p3[ci] = fma(w3[h], bch, p3[ci]);
+#pragma unroll
+              for (int e = 0; e < NB; ++e) pb[e][ci] = fma(dd[h] * ab[e][h], bch, pb[e][ci]);
+            }
+          }
+        };
+        auto trip_k = [&](auto Kc) AINL { pair_k(Kc, 0); pair_k(Kc, 1); };
+        switch (nact) {
+          case 0: trip_k(IC<0>{}); break;
+          case 1: trip_k(IC<1>{}); break;
+          case 2: if constexpr (NTW >= 2) trip_k(IC<2>{}); break;
+          case 3: if constexpr (NTW >= 3) trip_k(IC<3>{}); break;
+          case 4: if constexpr (NTW >= 4) trip_k(IC<4>{}); break;
+          case 5: if constexpr (NTW >= 5) trip_k(IC<5>{}); break;
+          case 6: if constexpr (NTW >= 6) trip_k(IC<6>{}); break;
+          case 7: if constexpr (NTW >= 7) trip_k(IC<7>{}); break;
+          case 8: if constexpr (NTW >= 8) trip_k(IC<8>{}); break;
+          case 9: if constexpr (NTW >= 9) trip_k(IC<9>{}); break;
+          default: if constexpr (NTW >= 10) trip_k(IC<10>{}); break;
+        }
+      }
+      __syncthreads();   // the ring region is reused (second set of partial n-vectors) once everybody is through the last chunk
+    } else {
+      // operands straight from global memory, software-pipelined one pair ahead (shapes without LDS room for the ring)
+      auto load_pair = [&](int pi, PairOps& o) AINL {
+        const int tr = pi >> 1, u = pi & 1;
+        const int tc = tcs[tr], rb = aoff[tr] + u * tc;
+        const int s0 = 4 * tr + 2 * u;
+        const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
+        o.tc = tc;
+        o.dd = *reinterpret_cast<const v2d*>(&aD[rix]); o.w1 = *reinterpret_cast<const v2d*>(&aW1[rix]);
+        o.w2 = *reinterpret_cast<const v2d*>(&aW2[rix]); o.w3 = *reinterpret_cast<const v2d*>(&aW3[rix]);
+#pragma unroll
+        for (int e = 0; e < NB; ++e) o.ab[e] = AB2_(e, rix);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) if (tJ[t] < tc) { o.bi[t] = opnd(rb + tI[t]); o.bj[t] = opnd(rb + tJ[t]); }
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) if (w + W * ci < tc) o.bc[ci] = opnd(rb + w + W * ci);
+      };
       const int npair = 2 * ntr;
       PairOps cur, nxt;
       if (npair > 0) load_pair(0, cur);
@@ -878,6 +1018,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
         do_pair(cur);
         cur = nxt;
       }
+      if (NB > 0) __syncthreads();   // the border sums of every wave are in the scratch
     }
 #pragma unroll
     for (int ci = 0; ci < CW; ++ci) {
@@ -889,16 +1030,15 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
         for (int e = 0; e < NB; ++e) { const double vb = q_sum(pb[e][ci]); if (q == 0) MB_(e, 16 * ct + c) = vb; }
       }
     }
-    if (NB > 0 && w == W - 1) {
-      // border scalars are identical on the 16 lanes of a group: sum the four groups, lane 0 writes
-#pragma unroll
-      for (int e = 0; e < NB; ++e) {
-        const double v1 = q_sum(pwb[0][e]), v2 = q_sum(pwb[1][e]), v3 = q_sum(pwb[2][e]);
-        if (lane == 0) { P1_(nc + e) = v1; P2_(nc + e) = v2; P3_(nc + e) = v3; }
-#pragma unroll
-        for (int f = 0; f < NB; ++f) {
-          const double sv = q_sum(f >= e ? sbb[e][f] : sbb[f][e]);
-          if (lane == 0) MB_(e, nc + f) = sv;
+    if constexpr (NB > 0) {
+      if (w == W - 1 && lane == 0) {   // the border sums of the sweep at the top (the pass's barriers lie in between)
+        int k_ = 0;
+        for (int e = 0; e < NB; ++e)
+          for (int f = e; f < NB; ++f) { double t_ = 0.0; for (int ww = 0; ww < W; ++ww) t_ += slds[oScr + ww * 96 + k_]; MB_(e, nc + f) = t_; MB_(f, nc + e) = t_; ++k_; }
+        for (int e = 0; e < NB; ++e) {
+          double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+          for (int ww = 0; ww < W; ++ww) { t1 += slds[oScr + ww * 96 + k_]; t2 += slds[oScr + ww * 96 + k_ + 1]; t3 += slds[oScr + ww * 96 + k_ + 2]; }
+          P1_(nc + e) = t1; P2_(nc + e) = t2; P3_(nc + e) = t3; k_ += 3;
         }
       }
     }
@@ -910,7 +1050,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     // ================= row phase 1: residuals, weights (only on entry; afterwards fused into the update sweep) =================
     if (it == 0) {
       double s_gap = 0, m_rp = 0;
-      row_weights(s_gap, m_rp);
+      for (int js = w; js < JT; js += W) row_weights(js, ld_row(js * 64 + lane), s_gap, m_rp);
       red_put(0, wave_sum(s_gap)); red_put(1, wave_max(m_rp));
       __syncthreads();
       gap = red_sum(0); rp_rel = red_max(1);
@@ -941,27 +1081,26 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     if (!(merit < INFINITY)) { flag = have_saved ? 2 : -1; break; }
     if (merit <= P.tol_loose && merit < saved_merit) {
       for (int i = tid; i < np; i += NTH) XS[i] = X_(i);
-#pragma unroll
-      for (int si = 0; si < SW; ++si) { const int js = w + W * si; if (js < JT) LAMS[js * 64 + lane] = st[si].zl - st[si].zu; }
+      for (int js = w; js < JT; js += W) {
+        const int ix = js * 64 + lane;
+        if (js < J) LAMS[ix] = aW3[ix]; else { const int i = (js - J) * 64 + lane; LAMS[ix] = i < np ? LV_(i) : 0.0; }
+      }
       have_saved = 1; saved_merit = merit;
     } else if (merit > P.tol_loose && rp_rel <= P.tol_loose && gap_rel <= P.tol_loose) {
       // Only the dual residual is in the way: repair the certificate of a *copy* of the iterate by moving r_d into the
       // bound multipliers, where a finite bound of the right sign exists.
       double dgap_l = 0, m_rd2_l = 0;
-#pragma unroll
-      for (int si = 0; si < SW; ++si) {
-        const int js = w + W * si;
-        if (js >= J && js < JT) {
-          const int i = (js - J) * 64 + lane;
-          if (i < n) {
-            const RowState& r = st[si];
-            const double lam = r.zl - r.zu, gz = P3_(i) + lam, rr = HX_(i) + G_(i) - gz, lam2 = lam + rr;
-            const bool ok = lam2 >= 0 ? r.l > -INFINITY : r.u < INFINITY;
-            if (ok) dgap_l += fabs(rr) * fmax(0.0, lam2 >= 0 ? r.v - r.l : r.u - r.v);
-            else {
-              const double sc = fmax(1.0, fmax(fabs(G_(i)), fmax(fabs(HX_(i)), fabs(gz))));
-              m_rd2_l = fmax(m_rd2_l, fabs(rr) / sc);
-            }
+      for (int js = w; js < JT; js += W) {
+        if (js < J) continue;
+        const int i = (js - J) * 64 + lane, ix = js * 64 + lane;
+        if (i < n) {
+          const double l = aL[ix], u = aU[ix], v = aV[ix];
+          const double lam = LV_(i), gz = P3_(i) + lam, rr = HX_(i) + G_(i) - gz, lam2 = lam + rr;
+          const bool ok = lam2 >= 0 ? l > -INFINITY : u < INFINITY;
+          if (ok) dgap_l += fabs(rr) * fmax(0.0, lam2 >= 0 ? v - l : u - v);
+          else {
+            const double sc = fmax(1.0, fmax(fabs(G_(i)), fmax(fabs(HX_(i)), fabs(gz))));
+            m_rd2_l = fmax(m_rd2_l, fabs(rr) / sc);
           }
         }
       }
@@ -971,20 +1110,19 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
       red_next();
       if (merit2 <= P.tol_loose && merit2 < saved_merit) {
         for (int i = tid; i < np; i += NTH) XS[i] = X_(i);
-#pragma unroll
-        for (int si = 0; si < SW; ++si) {
-          const int js = w + W * si;
-          if (js < J) LAMS[js * 64 + lane] = st[si].zl - st[si].zu;
-          else if (js < JT) {
+        for (int js = w; js < JT; js += W) {
+          const int ix = js * 64 + lane;
+          if (js < J) LAMS[ix] = aW3[ix];
+          else {
             const int i = (js - J) * 64 + lane;
             double lf = 0.0;
             if (i < n) {
-              const RowState& r = st[si];
-              const double lam = r.zl - r.zu, rr = HX_(i) + G_(i) - (P3_(i) + lam), lam2 = lam + rr;
-              const bool ok = lam2 >= 0 ? r.l > -INFINITY : r.u < INFINITY;
+              const double l = aL[ix], u = aU[ix];
+              const double lam = LV_(i), rr = HX_(i) + G_(i) - (P3_(i) + lam), lam2 = lam + rr;
+              const bool ok = lam2 >= 0 ? l > -INFINITY : u < INFINITY;
               lf = ok ? lam2 : lam;
             }
-            LAMS[js * 64 + lane] = lf;
+            LAMS[ix] = lf;
           }
         }
         have_saved = 1; saved_merit = merit2;
@@ -1018,17 +1156,25 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
             if (i == nc + e) v += DV_(i);
             P.dump[i * n + nc + e] = v; P.dump[(nc + e) * n + i] = v;
           }
-        for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1_(i); P.dump[n * n + n + i] = P2_(i); P.dump[n * n + 2 * n + i] = P3_(i); P.dump[n * n + 3 * n + i] = HX_(i); }
+        for (int i = lane; i < n; i += 64) { P.dump[n * n + i] = P1_(i); P.dump[n * n + n + i] = P2_(i); P.dump[n * n + 2 * n + i] = P3_(i); P.dump[n * n + 3 * n + i] = HX_(i);
+                                             P.dump[n * n + 4 * n + i] = R1_(i); P.dump[n * n + 5 * n + i] = R2_(i); }   // right-hand sides of the two step directions
       }
     }
+    __syncthreads();
 #endif
     STAMP(4);
-    if (factor_solve2()) {
+    if (factor_solve2(true)) {
       flag = (res_ok || have_saved) ? 2 : -1;
-      if (flag == -1 && P.polish && rp_rel <= P.tol_loose && gap_rel <= P.tol_loose) flag = 4;
+      // the factorisation broke down (weights ~1e24) on an iterate that is nearly primal feasible and complementary: its working
+      // set is usually the right one already, so the refinement gets a try (flag 4 -> 0 if accepted, else -1)
+      if (flag == -1 && P.polish && rp_rel <= QP_BREAKDOWN_TRY_TOL && gap_rel <= QP_BREAKDOWN_TRY_TOL) flag = 4;
       break;
     }
     STAMP(7);
+#ifdef QP_DEBUG_DUMP
+    if (P.dump && b == 0 && P.dump_stage == 1 && it == P.dump_iter && w == 0)   // debug: the two step directions M^-1 R1, M^-1 R2
+      for (int i = lane; i < n; i += 64) { P.dump[n * n + 6 * n + i] = R1_(i); P.dump[n * n + 7 * n + i] = R2_(i); }
+#endif
     if (res_ok) {  // Newton-decrement test in the caller's coordinates
       double dm = 0, xm = 1.0;
       for (int i = lane; i < n; i += 64) { dm = fmax(dm, fabs(R1_(i) * EV_(i))); xm = fmax(xm, fabs(X_(i) * EV_(i))); }
@@ -1037,49 +1183,47 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     }
     if (it >= P.max_iter) { flag = have_saved ? 2 : 1; break; }
 
-    // ================= pass 2 (my slots): va = G dxa, vc = G dxc; fused: WP[0] = A~' w_cor =================
+    // ================= pass 2 (my slots): va = G dxa, vc = G dxc; fused: WP[w] = A~' w_cor =================
     {
-      // corrector coefficients of my A rows into the exchange arrays (all waves are past pass 1: barriers since)
-#pragma unroll
-      for (int si = 0; si < SW; ++si) {
-        const int js = w + W * si;
-        if (js < J) {
-          const RowState& r = st[si];
-          const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
-          const int ix = js * 64 + lane;
-          EX_(0, ix) = hl ? r.v - r.l - r.tl : 0.0; EX_(1, ix) = r.dl; EX_(2, ix) = hl ? r.dl / r.tl : 0.0;
-          EX_(3, ix) = hu ? r.u - r.v - r.tu : 0.0; EX_(4, ix) = r.du; EX_(5, ix) = hu ? r.du / r.tu : 0.0;
-        }
-      }
       double v[2][T], vb[2][NBB], pc[T], pcb[NBB];
 #pragma unroll
       for (int t = 0; t < T; ++t) { v[0][t] = R1_(16 * t + c); v[1][t] = R2_(16 * t + c); pc[t] = 0.0; }
 #pragma unroll
       for (int f = 0; f < NBB; ++f) { vb[0][f] = NB ? R1_(nc + f) : 0.0; vb[1][f] = NB ? R2_(nc + f) : 0.0; pcb[f] = 0.0; }
-#pragma unroll
-      for (int si = 0; si < SW; ++si) {
-        SLOT_PASS_BEGIN(si)
-          const v2d rpl = *reinterpret_cast<const v2d*>(&EX_(0, rix)), cb1 = *reinterpret_cast<const v2d*>(&EX_(1, rix)), cc1 = *reinterpret_cast<const v2d*>(&EX_(2, rix));
-          const v2d rpu = *reinterpret_cast<const v2d*>(&EX_(3, rix)), cb2 = *reinterpret_cast<const v2d*>(&EX_(4, rix)), cc2 = *reinterpret_cast<const v2d*>(&EX_(5, rix));
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            double ds0 = 0.0, ds1 = 0.0;
-#pragma unroll
-            for (int t = 0; t < T; ++t) { ds0 = fma(bq[t][h], v[0][t], ds0); ds1 = fma(bq[t][h], v[1][t], ds1); }
-            ds0 = grp16_sum(ds0); ds1 = grp16_sum(ds1);
-#pragma unroll
-            for (int f = 0; f < NB; ++f) { const double a_ = AB_(f, rix + h); ds0 = fma(a_, vb[0][f], ds0); ds1 = fma(a_, vb[1][f], ds1); }
-            if (c == ((s0 + h) & 15)) { st[si].va = ds0; st[si].vc = ds1; }
-            const double dl_ = ds0 + rpl[h], du_ = rpu[h] - ds0;
-            const double wc = dl_ * fma(cc1[h], dl_, cb1[h]) - du_ * fma(cc2[h], du_, cb2[h]);
-#pragma unroll
-            for (int t = 0; t < T; ++t) pc[t] = fma(wc, bq[t][h], pc[t]);
-#pragma unroll
-            for (int f = 0; f < NB; ++f) pcb[f] = fma(wc, AB_(f, rix + h), pcb[f]);
+      for (int js = w; js < JT; js += W) {
+        const int ix = js * 64 + lane;
+        if (js < J) {
+          {   // corrector coefficients of this slot's rows into the wave's stage
+            const Row r = ld_row(ix);
+            const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
+            const double dl = hl ? r.zl / r.tl : 0.0, du = hu ? r.zu / r.tu : 0.0;
+            CWS_(0, lane) = hl ? r.v - r.l - r.tl : 0.0; CWS_(1, lane) = dl; CWS_(2, lane) = hl ? dl / r.tl : 0.0;
+            CWS_(3, lane) = hu ? r.u - r.v - r.tu : 0.0; CWS_(4, lane) = du; CWS_(5, lane) = hu ? du / r.tu : 0.0;
           }
-        SLOT_PASS_END
-        const int js = w + W * si;
-        if (js >= J && js < JT) { const int i = (js - J) * 64 + lane; st[si].va = i < n ? R1_(i) : 0.0; st[si].vc = i < n ? R2_(i) : 0.0; }
+          double ka = 0.0, kc = 0.0;
+          slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
+            const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15), cix = q * 16 + (s0 & 15);
+            const v2d rpl = *reinterpret_cast<const v2d*>(&CWS_(0, cix)), cb1 = *reinterpret_cast<const v2d*>(&CWS_(1, cix)), cc1 = *reinterpret_cast<const v2d*>(&CWS_(2, cix));
+            const v2d rpu = *reinterpret_cast<const v2d*>(&CWS_(3, cix)), cb2 = *reinterpret_cast<const v2d*>(&CWS_(4, cix)), cc2 = *reinterpret_cast<const v2d*>(&CWS_(5, cix));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              double ds0 = 0.0, ds1 = 0.0;
+#pragma unroll
+              for (int t = 0; t < T; ++t) { ds0 = fma(bq[t][h], v[0][t], ds0); ds1 = fma(bq[t][h], v[1][t], ds1); }
+              ds0 = grp16_sum(ds0); ds1 = grp16_sum(ds1);
+#pragma unroll
+              for (int f = 0; f < NB; ++f) { const double a_ = AB_(f, rix + h); ds0 = fma(a_, vb[0][f], ds0); ds1 = fma(a_, vb[1][f], ds1); }
+              if (c == ((s0 + h) & 15)) { ka = ds0; kc = ds1; }
+              const double dl_ = ds0 + rpl[h], du_ = rpu[h] - ds0;
+              const double wc = dl_ * fma(cc1[h], dl_, cb1[h]) - du_ * fma(cc2[h], du_, cb2[h]);
+#pragma unroll
+              for (int t = 0; t < T; ++t) pc[t] = fma(wc, bq[t][h], pc[t]);
+#pragma unroll
+              for (int f = 0; f < NB; ++f) pcb[f] = fma(wc, AB_(f, rix + h), pcb[f]);
+            }
+          });
+          aVA[ix] = ka; aVC[ix] = kc;
+        } else { const int i = (js - J) * 64 + lane; aVA[ix] = i < n ? R1_(i) : 0.0; aVC[ix] = i < n ? R2_(i) : 0.0; }
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) { const double pv = q_sum(pc[t]); if (q == 0) slds[oWP + w * np + 16 * t + c] = pv; }
@@ -1093,27 +1237,29 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     STAMP(8);
     // ================= row phase 2: affine step length, sigma, second-order weights of the variable rows =================
     double a_aff = 1.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      const int js = w + W * si;
-      const RowState& r = st[si];
+    for (int js = w; js < JT; js += W) {
+      const int ix = js * 64 + lane;
+      const Row r = ld_row(ix);
+      const double va = aVA[ix];
       const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
       double wv = 0.0;
       if (hl) {
-        const double dt = r.va + (r.v - r.l - r.tl), dz = -r.zl - r.dl * dt;
+        const double dl = r.zl / r.tl;
+        const double dt = va + (r.v - r.l - r.tl), dz = -r.zl - dl * dt;
         if (dt < 0) a_aff = fmin(a_aff, -r.tl / dt);
         if (dz < 0) a_aff = fmin(a_aff, -r.zl / dz);
         s1 += r.tl * dz + r.zl * dt; s2 += dt * dz;
         wv -= dt * dz / r.tl;
       }
       if (hu) {
-        const double dt = -r.va + (r.u - r.v - r.tu), dz = -r.zu - r.du * dt;
+        const double du = r.zu / r.tu;
+        const double dt = -va + (r.u - r.v - r.tu), dz = -r.zu - du * dt;
         if (dt < 0) a_aff = fmin(a_aff, -r.tu / dt);
         if (dz < 0) a_aff = fmin(a_aff, -r.zu / dz);
         s1 += r.tu * dz + r.zu * dt; s2 += dt * dz;
         wv += dt * dz / r.tu;
       }
-      if (js >= J && js < JT) { const int i = (js - J) * 64 + lane; if (i < np) W1V_(i) = wv; }   // (A rows: fused in pass 2)
+      if (js >= J) { const int i = (js - J) * 64 + lane; if (i < np) W1V_(i) = wv; }   // (A rows: fused in pass 2)
     }
     red_put(0, wave_min(a_aff)); red_put(1, wave_sum(s1)); red_put(2, wave_sum(s2));
     __syncthreads();
@@ -1136,35 +1282,37 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
       solve1(VEC(V_DX));
       STAMP(10);
       // ================= pass 3 (my slots): G dx_cor =================
-      rows_Av(VEC(V_DX), [&](int si) AINL -> double& { return st[si].wc; });
+      rows_Av(VEC(V_DX), aWC);
     } else {   // no corrector this iteration
       for (int i = tid; i < np; i += NTH) DX_(i) = 0.0;
-#pragma unroll
-      for (int si = 0; si < SW; ++si) st[si].wc = 0.0;
+      for (int js = w; js < JT; js += W) aWC[js * 64 + lane] = 0.0;
     }
     STAMP(11);
     // ================= row phase 3: step length (Mehrotra heuristic on the blocking pair) =================
     double amax = 1e300, bp = 0, bdp = 0, bd = 0, bdd = 0, q1 = 0.0, q2 = 0.0;
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      RowState& r = st[si];
+    for (int js = w; js < JT; js += W) {
+      const int ix = js * 64 + lane;
+      const Row r = ld_row(ix);
+      const double va = aVA[ix];
       const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
-      const double dv = r.va + smu * r.vc + r.wc;
-      r.vc = dv;  // keep the full G dx for the update
+      const double dv = va + smu * aVC[ix] + aWC[ix];
+      aVC[ix] = dv;  // keep the full G dx for the update
       if (hl) {
+        const double dl = r.zl / r.tl;
         const double rpl = r.v - r.l - r.tl;
-        const double dta = r.va + rpl, dza = -r.zl - r.dl * dta;
+        const double dta = va + rpl, dza = -r.zl - dl * dta;
         const double cl = smu - cw * dta * dza;
-        const double dt = dv + rpl, dz = -r.zl + cl / r.tl - r.dl * dt;
+        const double dt = dv + rpl, dz = -r.zl + cl / r.tl - dl * dt;
         if (dt < 0 && -r.tl / dt < amax) { amax = -r.tl / dt; bp = r.tl; bdp = dt; bd = r.zl; bdd = dz; }
         if (dz < 0 && -r.zl / dz < amax) { amax = -r.zl / dz; bp = r.zl; bdp = dz; bd = r.tl; bdd = dt; }
         q1 += r.tl * dz + r.zl * dt; q2 += dt * dz;
       }
       if (hu) {
+        const double du = r.zu / r.tu;
         const double rpu = r.u - r.v - r.tu;
-        const double dta = -r.va + rpu, dza = -r.zu - r.du * dta;
+        const double dta = -va + rpu, dza = -r.zu - du * dta;
         const double cu = smu - cw * dta * dza;
-        const double dt = -dv + rpu, dz = -r.zu + cu / r.tu - r.du * dt;
+        const double dt = -dv + rpu, dz = -r.zu + cu / r.tu - du * dt;
         if (dt < 0 && -r.tu / dt < amax) { amax = -r.tu / dt; bp = r.tu; bdp = dt; bd = r.zu; bdd = dz; }
         if (dz < 0 && -r.zu / dz < amax) { amax = -r.zu / dz; bp = r.zu; bdp = dz; bd = r.tu; bdd = dt; }
         q1 += r.tu * dz + r.zu * dt; q2 += dt * dz;
@@ -1197,32 +1345,37 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     STAMP(12);
     // ================= update, fused with the residual / weight phase of the next iteration =================
     double xn = 0, zn = 0, s_gap = 0, m_rp = 0;
-#pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      RowState& r = st[si];
+    for (int js = w; js < JT; js += W) {
+      const int ix = js * 64 + lane;
+      Row r = ld_row(ix);
+      const double va = aVA[ix], dv = aVC[ix];
       const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
-      const double dv = r.vc;
       if (hl) {
+        const double dl = r.zl / r.tl;
         const double rpl = r.v - r.l - r.tl;
-        const double dta = r.va + rpl, dza = -r.zl - r.dl * dta;
+        const double dta = va + rpl, dza = -r.zl - dl * dta;
         const double cl = smu - cw * dta * dza;
-        const double dt = dv + rpl, dz = -r.zl + cl / r.tl - r.dl * dt;
+        const double dt = dv + rpl, dz = -r.zl + cl / r.tl - dl * dt;
         r.tl += alpha * dt; r.zl += alpha * dz;
+        aTL[ix] = r.tl; aZL[ix] = r.zl;
         zn = fmax(zn, r.zl);
       }
       if (hu) {
+        const double du = r.zu / r.tu;
         const double rpu = r.u - r.v - r.tu;
-        const double dta = -r.va + rpu, dza = -r.zu - r.du * dta;
+        const double dta = -va + rpu, dza = -r.zu - du * dta;
         const double cu = smu - cw * dta * dza;
-        const double dt = -dv + rpu, dz = -r.zu + cu / r.tu - r.du * dt;
+        const double dt = -dv + rpu, dz = -r.zu + cu / r.tu - du * dt;
         r.tu += alpha * dt; r.zu += alpha * dz;
+        aTU[ix] = r.tu; aZU[ix] = r.zu;
         zn = fmax(zn, r.zu);
       }
       r.v += alpha * dv;
+      aV[ix] = r.v;
+      row_weights(js, r, s_gap, m_rp);
     }
     // full direction dx = dxa + smu*dxc + dxcor (R1, R2, DX are stable since the last barrier)
     for (int i = tid; i < n; i += NTH) { const double xv = X_(i) + alpha * (R1_(i) + smu * R2_(i) + DX_(i)); X_(i) = xv; xn = fmax(xn, fabs(xv)); }
-    row_weights(s_gap, m_rp);
     const double rp_prev = rp_rel;
     red_put(0, wave_sum(s_gap)); red_put(1, wave_max(m_rp)); red_put(2, wave_max(xn)); red_put(3, wave_max(zn));
     __syncthreads();
@@ -1234,42 +1387,334 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
     // primal residual it is the signature of an infeasible QP (-2); otherwise an internal failure (-1)
     if (xn > 1e13) { flag = rp_prev > 1e-6 ? -2 : (fval < -1e13 ? -3 : -1); break; }
     if (zn > 1e15 && rp_prev > 1e-6) { flag = -2; break; }
-    if (stall > (have_saved ? 5 : 25)) { flag = have_saved ? 2 : (rp_prev > 1e-6 ? -2 : 1); break; }
+    if (stall > (have_saved ? 5 : 25)) { flag = have_saved ? 2 : (rp_prev > 1e-6 ? -2 : (P.polish ? 5 : 1)); break; }   // 5: stalled, the refinement may still certify (else 1)
   }
   __syncthreads();
 
-  // ---- outputs ----
-  double lam_out[SW];
-#pragma unroll
-  for (int si = 0; si < SW; ++si) lam_out[si] = st[si].zl - st[si].zu;
+  // ---- the returned point ----
+  // The last iterate (or the best saved one) is returned whatever the exit code: the reference keeps driving on whatever the
+  // solver handed back (main.m:163-175).  Multipliers of the returned point: row array W3 (A rows) / LDS vector LV (bounds).
+  const bool v_current = flag == 0 || flag == 4;   // aV still equals G x and fval_s is the objective at x (not so after a restore / an update)
   if (flag == 2) {  // restore the best iterate that met tol_loose
     for (int i = tid; i < np; i += NTH) X_(i) = XS[i];
-#pragma unroll
-    for (int si = 0; si < SW; ++si) { const int js = w + W * si; if (js < JT) lam_out[si] = LAMS[js * 64 + lane]; }
+    for (int js = w; js < JT; js += W) {
+      const int ix = js * 64 + lane;
+      if (js < J) aW3[ix] = LAMS[ix]; else { const int i = (js - J) * 64 + lane; if (i < np) LV_(i) = LAMS[ix]; }
+    }
     flag = 0; merit_s = saved_merit;
   }
   __syncthreads();
-  if (flag == 4) flag = -1;   // not certified (this kernel has no active-set refinement yet)
-  const bool have_x = true;   // the last iterate is returned whatever the exit code (main.m:163-175 keeps driving on it)
-  double* xo = P.x + (size_t)b * n;
-  for (int i = tid; i < n; i += NTH) xo[i] = have_x ? X_(i) * EV_(i) : NAN;
-  if (P.lambda) {
-    double* lo = P.lambda + (size_t)b * (n + m);
-    const double* __restrict__ Fs = ws + d.off_F;
+
+  // ---- active-set refinement: from the interior-point point to the vertex an active-set solver (qpOASES) stops at ----
+  // Same algorithm as the one-wavefront kernel (qp_solver.hip, where the construction is described): working set W from the
+  // multipliers (side active iff |lambda| exceeds its slack); active bounds pinned (1e16 on the diagonal, zero right-hand side);
+  // active rows A_W z = b by conjugate gradients on the dual of the augmented problem, operator S = A_W M^-1 A_W' with
+  // M = H~ + pin + rho A_W'A_W (resident Cholesky factor); one fused stream over A~ per CG step; up to QP_REFINE_ATTEMPTS attempts
+  // with add / drop corrections; accepted only if a fresh evaluation says the point is a KKT point of the full QP.
+  // Row arrays of this phase (A rows AND variable rows, owner layout): PS working-set side (+1 lower, -1 upper), PA rho on the
+  // working set, PB target, PY multiplier, PC constraint residual, PP CG direction, QV = A~ (vector), YV = y - rho c / bound multiplier.
+  // n-vectors: Z = R2 (the point), ATR = R1, ATP = P3 (A_W'r, A_W'p by recurrence), DX work vector, P1 / P2 pass outputs;
+  // variable rows as n-vectors: DV pin weight (read by factor_solve2), W1V side, W2V bound value.
+  if ((flag == 0 || flag == 4 || flag == 5) && P.polish) {
+    const double rho = 1e6, pin = 1e16, rinv = 1.0 / rho;
+    double* PS = rowarr(R_CB2); double* PA = rowarr(R_CB1); double* PB = rowarr(R_RPL);
+    double* PY = rowarr(R_CC1); double* PC = rowarr(R_RPU); double* PP = rowarr(R_CC2);
+    double* QV = aVA; double* YV = aVC;
+    if (!v_current) rows_Av(VEC(V_X), aV);
+    for (int js = w; js < JT; js += W) {
+      const int ix = js * 64 + lane;
+      const double l = aL[ix], u = aU[ix], v = aV[ix];
+      double lam;
+      if (js < J) lam = aW3[ix]; else { const int i = (js - J) * 64 + lane; lam = i < np ? LV_(i) : 0.0; }
+      const bool lo = l > -INFINITY && lam > 0 && lam > fabs(v - l);
+      const bool up = u < INFINITY && lam < 0 && -lam > fabs(u - v);
+      PS[ix] = lo ? 1.0 : (up ? -1.0 : 0.0); PY[ix] = ((lo || up) && js < J) ? lam : 0.0;
+    }
+    for (int i = tid; i < np; i += NTH) XS[i] = X_(i);   // z of the refinement between attempts (the fall-back copy is no longer needed)
+    __syncthreads();
+
+    // fused pass of the refinement over my slots: q = A~ v (-> QV), pen = cf0 (q - cf1), y^ = cf2 - pen (-> YV),
+    // P1 = A~' y^, P2 = A~' pen.  mode 0: evaluation at (z, y), cf = (PA, PB, PY); mode 1: CG step, cf = (PA, 0, 0).
+    auto pass_fused = [&](int oV, int mode) AINL {
+      double v[T], vb[NBB], pc[T], pd[T], pcb[NBB], pdb[NBB];
 #pragma unroll
-    for (int si = 0; si < SW; ++si) {
-      const int js = w + W * si;
+      for (int t = 0; t < T; ++t) { v[t] = slds[oV + 16 * t + c]; pc[t] = 0.0; pd[t] = 0.0; }
+#pragma unroll
+      for (int f = 0; f < NBB; ++f) { vb[f] = NB ? slds[oV + nc + f] : 0.0; pcb[f] = 0.0; pdb[f] = 0.0; }
+      for (int js = w; js < J; js += W) {
+        const int ix = js * 64 + lane;
+        CWS_(0, lane) = PA[ix]; CWS_(1, lane) = mode == 0 ? PB[ix] : 0.0; CWS_(2, lane) = mode == 0 ? PY[ix] : 0.0;
+        double kq = 0.0, ky = 0.0;
+        slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
+          const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15), cix = q * 16 + (s0 & 15);
+          const v2d c0 = *reinterpret_cast<const v2d*>(&CWS_(0, cix)), c1 = *reinterpret_cast<const v2d*>(&CWS_(1, cix)), c2 = *reinterpret_cast<const v2d*>(&CWS_(2, cix));
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double dsum = 0.0;
+#pragma unroll
+            for (int t = 0; t < T; ++t) dsum = fma(bq[t][h], v[t], dsum);
+            dsum = grp16_sum(dsum);
+#pragma unroll
+            for (int f = 0; f < NB; ++f) dsum = fma(AB_(f, rix + h), vb[f], dsum);
+            const double pen = c0[h] * (dsum - c1[h]);
+            const double ynew = c2[h] - pen;
+            if (c == ((s0 + h) & 15)) { kq = dsum; ky = ynew; }
+#pragma unroll
+            for (int t = 0; t < T; ++t) { pc[t] = fma(ynew, bq[t][h], pc[t]); pd[t] = fma(pen, bq[t][h], pd[t]); }
+#pragma unroll
+            for (int f = 0; f < NB; ++f) { const double a_ = AB_(f, rix + h); pcb[f] = fma(ynew, a_, pcb[f]); pdb[f] = fma(pen, a_, pdb[f]); }
+          }
+        });
+        QV[ix] = kq; YV[ix] = ky;
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const double pv = q_sum(pc[t]), dv_ = q_sum(pd[t]);
+        if (q == 0) { slds[oWP + w * np + 16 * t + c] = pv; slds[oP2 + w * np + 16 * t + c] = dv_; }
+      }
+      {
+        double pvb = 0.0, dvb = 0.0;
+#pragma unroll
+        for (int f = 0; f < NB; ++f) { const double s = q_sum(pcb[f]), s2_ = q_sum(pdb[f]); if (lane == f) { pvb = s; dvb = s2_; } }
+        if (NB > 0 && lane < 16) { slds[oWP + w * np + nc + lane] = pvb; slds[oP2 + w * np + nc + lane] = dvb; }
+      }
+      __syncthreads();
+      for (int i = tid; i < np; i += NTH) {
+        double s = 0.0, s2_ = 0.0;
+        for (int ww = 0; ww < W; ++ww) { s += slds[oWP + ww * np + i]; s2_ += slds[oP2 + ww * np + i]; }
+        P1_(i) = s; P2_(i) = s2_;
+      }
+      __syncthreads();
+    };
+    // gradient of the augmented Lagrangian at (z, y): QV = A~z, YV = y - rho c, P1 = A~'y^, P2 = rho A_W'c, HX = H~z
+    auto eval_zy = [&]() AINL { pass_fused(VEC(V_R2), 0); hx_keep(VEC(V_R2)); };
+    // index of the variable row i in the owner-layout row arrays
+    auto vix = [&](int i) AINL { return (J + (i >> 6)) * 64 + (i & 63); };
+
+    for (int attempt = 0; attempt < QP_REFINE_ATTEMPTS && flag_polished <= 0; ++attempt) {
+      for (int js = w; js < JT; js += W) {
+        const int ix = js * 64 + lane;
+        const double sd = PS[ix];
+        const double tgt = sd > 0 ? aL[ix] : (sd < 0 ? aU[ix] : 0.0);
+        PA[ix] = sd != 0.0 ? rho : 0.0; PB[ix] = tgt; PC[ix] = 0.0; PP[ix] = 0.0;
+        if (js < J) { aD[ix] = sd != 0.0 ? rho : 0.0; aW1[ix] = 0.0; aW2[ix] = 0.0; }   // (W3 keeps the interior-point multipliers: they are returned if the refinement is rejected)
+        else { const int i = (js - J) * 64 + lane; if (i < np) { DV_(i) = sd != 0.0 ? pin : 0.0; W1V_(i) = sd; W2V_(i) = tgt; } }
+      }
+      __syncthreads();
+      acc_init();
+      pass_syrk();
+      for (int i = tid; i < np; i += NTH) { R1_(i) = 0.0; R2_(i) = 0.0; }
+      __syncthreads();
+      bool pok = factor_solve2(false) == 0, retry = false;
+      if (!pok) { flag_polished = -5; break; }
+      // z: the point reached so far, pinned variables on their bounds
+      for (int i = tid; i < np; i += NTH) R2_(i) = (i < n && W1V_(i) != 0.0) ? W2V_(i) : XS[i];
+      __syncthreads();
+      eval_zy();
+      for (int i = tid; i < np; i += NTH) DX_(i) = (i < n && W1V_(i) == 0.0) ? -(HX_(i) + G_(i) - P1_(i)) : 0.0;
+      __syncthreads();
+      solve1(VEC(V_DX));
+      for (int i = tid; i < n; i += NTH) if (W1V_(i) == 0.0) R2_(i) += DX_(i);
+      __syncthreads();
+      eval_zy();   // c(z): QV = A~z; P2 = rho A_W'c
+      double rs_l = 0.0;
+      for (int js = w; js < J; js += W) {
+        const int ix = js * 64 + lane;
+        const double cc_ = PA[ix] != 0.0 ? QV[ix] - PB[ix] : 0.0;
+        PC[ix] = cc_; PP[ix] = -cc_; rs_l = fma(cc_, cc_, rs_l);
+      }
+      red_put(0, wave_sum(rs_l));
+      for (int i = tid; i < np; i += NTH) { const double a_ = -P2_(i) * rinv; R1_(i) = a_; P3_(i) = a_; }   // ATR, ATP
+      __syncthreads();
+      double rs = red_sum(0);
+      red_next();
+      for (int cgit = 0; cgit < 12 && pok; ++cgit) {
+        double m_eq = 0.0, m_cy = 0.0;
+        for (int js = w; js < J; js += W) {
+          const int ix = js * 64 + lane;
+          const double pc_ = PC[ix];
+          m_eq = fmax(m_eq, fabs(pc_) / fmax(1.0, fabs(PB[ix])));
+          m_cy = fmax(m_cy, fabs(pc_ * PY[ix]));
+        }
+        red_put(0, wave_max(m_eq)); red_put(1, wave_max(m_cy));
+        __syncthreads();
+        m_eq = red_max(0); m_cy = red_max(1);
+        red_next();
+        if (m_eq <= 1e-11 && m_cy <= 1e-11 * fmax(1.0, fabs(fval_s))) break;
+        if (cgit == 11) { pok = false; flag_polished = -6; break; }
+        for (int i = tid; i < np; i += NTH) DX_(i) = (i < n && W1V_(i) == 0.0) ? P3_(i) : 0.0;
+        __syncthreads();
+        solve1(VEC(V_DX));                            // w = M^-1 A_W'p
+        pass_fused(VEC(V_DX), 1);                     // QV = A~w; P2 = rho A_W'(A_W w)
+        double pq_l = 0.0;
+        for (int js = w; js < J; js += W) { const int ix = js * 64 + lane; if (PA[ix] != 0.0) pq_l = fma(PP[ix], QV[ix], pq_l); }
+        red_put(0, wave_sum(pq_l));
+        __syncthreads();
+        const double pq = red_sum(0);
+        red_next();
+        if (!(pq > 0.0) || !(rs > 0.0)) {   // dependent / inconsistent working set: drop the row that carries the stalled direction
+          pok = false; flag_polished = -7;
+          if (attempt < QP_REFINE_ATTEMPTS - 1) {
+            double my = 0.0; int myix = -1;
+            for (int js = w; js < J; js += W) { const int ix = js * 64 + lane; if (PA[ix] != 0.0 && fabs(PP[ix]) > my) { my = fabs(PP[ix]); myix = ix; } }
+            red_put(0, wave_max(my));
+            __syncthreads();
+            const double mx = red_max(0);
+            red_next();
+            if (mx > 0.0 && my == mx && myix >= 0) { PS[myix] = 0.0; PY[myix] = 0.0; }
+            for (int i = tid; i < np; i += NTH) XS[i] = R2_(i);
+            __syncthreads();
+            retry = true;
+          }
+          break;
+        }
+        const double alpha_ = rs / pq;
+        double rsn_l = 0.0;
+        for (int js = w; js < J; js += W) {
+          const int ix = js * 64 + lane;
+          if (PA[ix] != 0.0) {
+            PY[ix] = fma(alpha_, PP[ix], PY[ix]);
+            const double cc_ = fma(alpha_, QV[ix], PC[ix]);
+            PC[ix] = cc_; rsn_l = fma(cc_, cc_, rsn_l);
+          }
+        }
+        red_put(0, wave_sum(rsn_l));
+        __syncthreads();
+        const double rsn = red_sum(0);
+        red_next();
+        const double beta_ = rsn / rs;
+        for (int js = w; js < J; js += W) { const int ix = js * 64 + lane; if (PA[ix] != 0.0) PP[ix] = fma(beta_, PP[ix], -PC[ix]); }
+        for (int i = tid; i < np; i += NTH) {
+          if (i < n && W1V_(i) == 0.0) R2_(i) = fma(alpha_, DX_(i), R2_(i));
+          const double atr = fma(-alpha_ * rinv, P2_(i), R1_(i));
+          R1_(i) = atr;
+          P3_(i) = fma(beta_, P3_(i), atr);
+        }
+        rs = rsn;
+        __syncthreads();
+      }
+      if (pok) {
+        // fresh evaluation of the candidate (z, y): everything recomputed from a stream over A~ and H~
+        eval_zy();
+        double m_rd = 0, m_rp = 0, m_sg = 0, m_cp = 0, fl2 = 0;
+        for (int i = tid; i < n; i += NTH) {
+          const int ix = vix(i);
+          const double r = HX_(i) + G_(i) - P1_(i);                   // free variable: must vanish; pinned variable: its bound multiplier
+          const double sc = fmax(1.0, fmax(fabs(G_(i)), fmax(fabs(HX_(i)), fabs(P1_(i)))));
+          const double sd = W1V_(i), zi = R2_(i), l = aL[ix], u = aU[ix];
+          if (sd == 0.0) m_rd = fmax(m_rd, fabs(r) / sc);
+          else m_sg = fmax(m_sg, (sd > 0 ? -r : r) / sc);
+          YV[ix] = sd != 0.0 ? r : 0.0;                               // multiplier of the variable-bound row
+          double viol = 0.0;
+          if (l > -INFINITY && zi < l) viol = l - zi;
+          if (u < INFINITY && zi > u) viol = fmax(viol, zi - u);
+          m_rp = fmax(m_rp, viol / fmax(1.0, fabs(zi)));
+          fl2 += 0.5 * zi * HX_(i) + G_(i) * zi;
+        }
+        for (int js = w; js < J; js += W) {
+          const int ix = js * 64 + lane;
+          const double l = aL[ix], u = aU[ix], v = QV[ix], y = YV[ix], sd = PS[ix];
+          if (l > -INFINITY || u < INFINITY) {   // (padding rows carry infinite bounds)
+            double sc = fmax(1.0, fabs(v));
+            if (l > -INFINITY) sc = fmax(sc, fabs(l));
+            if (u < INFINITY) sc = fmax(sc, fabs(u));
+            double viol = 0.0;
+            if (sd != 0.0) { viol = fabs(v - PB[ix]); m_cp = fmax(m_cp, fabs(y) * viol); }
+            if (l > -INFINITY && v < l) viol = fmax(viol, l - v);
+            if (u < INFINITY && v > u) viol = fmax(viol, v - u);
+            m_rp = fmax(m_rp, viol / sc);
+            m_sg = fmax(m_sg, (sd > 0 ? -y : (sd < 0 ? y : 0.0)) / fmax(1.0, fabs(y)));
+          }
+        }
+        red_put(0, wave_max(m_rd)); red_put(1, wave_max(m_rp)); red_put(2, wave_max(m_sg)); red_put(3, wave_max(m_cp)); red_put(4, wave_sum(fl2));
+        __syncthreads();
+        m_rd = red_max(0); m_rp = red_max(1); m_sg = red_max(2); m_cp = red_max(3);
+        const double f2 = red_sum(4);
+        red_next();
+        // acceptance: relative stationarity 1e-8, feasibility and complementarity 1e-10, multipliers of the right sign (the same
+        // thresholds as the one-wavefront kernel)
+        pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8;
+        if (!pok) flag_polished = !(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3));
+        if (!pok && m_rd <= 1e-8 && attempt < QP_REFINE_ATTEMPTS - 1 && (m_rp > 1e-10 || m_sg > 1e-8)) {
+          // single correction of the working set: add the most violated inactive row, else drop the worst wrong-sign row
+          double my = 0.0; int myix = -1; double myside = 0.0;
+          const bool add = m_rp > 1e-10;
+          for (int js = w; js < JT; js += W) {
+            const int ix = js * 64 + lane;
+            const double l = aL[ix], u = aU[ix], sd = PS[ix];
+            if (!(l > -INFINITY || u < INFINITY)) continue;
+            double v;
+            if (js < J) v = QV[ix]; else { const int i = (js - J) * 64 + lane; v = i < np ? R2_(i) : 0.0; }
+            if (add) {
+              if (sd != 0.0) continue;
+              double sc = fmax(1.0, fabs(v));
+              if (js < J) { if (l > -INFINITY) sc = fmax(sc, fabs(l)); if (u < INFINITY) sc = fmax(sc, fabs(u)); }
+              const double vl = l > -INFINITY ? (l - v) / sc : -1.0, vu = u < INFINITY ? (v - u) / sc : -1.0;
+              const double vv = fmax(vl, vu);
+              if (vv > my) { my = vv; myix = ix; myside = vl >= vu ? 1.0 : -1.0; }
+            } else {
+              if (sd == 0.0) continue;
+              const double y = YV[ix];
+              const double sc = js < J ? fmax(1.0, fabs(y)) : 1.0;
+              const double sg = (sd > 0 ? -y : y) / sc;
+              if (sg > my) { my = sg; myix = ix; myside = 0.0; }
+            }
+          }
+          red_put(0, wave_max(my));
+          __syncthreads();
+          const double mx = red_max(0);
+          red_next();
+          if (mx > 0.0 && my == mx && myix >= 0) { PS[myix] = myside; PY[myix] = 0.0; }
+          __syncthreads();
+          for (int js = w; js < J; js += W) { const int ix = js * 64 + lane; PY[ix] = PS[ix] != 0.0 ? PY[ix] : 0.0; }
+          for (int i = tid; i < np; i += NTH) XS[i] = R2_(i);
+          __syncthreads();
+          continue;   // next attempt from the point reached (R2) with the corrected working set
+        }
+        if (!pok && !(m_rd <= 1e-8) && attempt < QP_REFINE_ATTEMPTS - 1 && m_rd <= 1e-4) {   // stationarity above the floor: one more exact step from here
+          for (int i = tid; i < np; i += NTH) XS[i] = R2_(i);
+          for (int js = w; js < J; js += W) { const int ix = js * 64 + lane; PY[ix] = PS[ix] != 0.0 ? YV[ix] : 0.0; }
+          __syncthreads();
+          continue;
+        }
+        if (!pok) break;
+        for (int i = tid; i < np; i += NTH) X_(i) = R2_(i);
+        for (int js = w; js < JT; js += W) {
+          const int ix = js * 64 + lane;
+          const double y = YV[ix], sd = PS[ix];
+          const double lam = sd > 0 ? fmax(y, 0.0) : (sd < 0 ? fmin(y, 0.0) : 0.0);
+          if (js < J) aW3[ix] = lam; else { const int i = (js - J) * 64 + lane; if (i < np) LV_(i) = lam; }
+        }
+        flag_polished = 1 + attempt;
+        fval_s = f2; merit_s = fmax(m_rd, fmax(m_rp, m_cp / fmax(1.0, fabs(f2))));
+        flag = 0;
+        __syncthreads();
+      } else if (!retry) break;
+    }   // attempts
+    __syncthreads();
+  }
+  if (flag == 4) flag = -1;   // not certified
+  if (flag == 5) flag = 1;
+
+  // ---- outputs ----
+  double* xo = P.x + (size_t)b * d.nu;       // caller's indexing (QpDims::nu: dummy padding variables are skipped)
+  for (int i = tid; i < n; i += NTH) { const int ui = qp_user_index(d, i); if (ui >= 0) xo[ui] = X_(i) * EV_(i); }
+  if (P.lambda) {
+    double* lo = P.lambda + (size_t)b * (d.nu + m);
+    const double* __restrict__ Fs = ws + d.off_F;
+    for (int js = w; js < JT; js += W) {
       if (js < J) {
         const int r = perm[js * 64 + lane];   // original row of this sorted position
-        if (r >= 0) lo[n + r] = have_x ? lam_out[si] * Fs[js * 64 + lane] : NAN;
-      } else if (js < JT) {
+        if (r >= 0) lo[d.nu + r] = aW3[js * 64 + lane] * Fs[js * 64 + lane];
+      } else {
         const int i = (js - J) * 64 + lane;
-        if (i < n) lo[i] = have_x ? lam_out[si] / EV_(i) : NAN;
+        const int ui = i < n ? qp_user_index(d, i) : -1;
+        if (ui >= 0) lo[ui] = LV_(i) / EV_(i);
       }
     }
   }
-  if (have_x) {  // objective at the returned point (H~, g~ scaling is objective preserving)
-    acc_init_hx(VEC(V_X));
+  if (!(v_current || flag_polished > 0)) {  // objective at the returned point (H~, g~ scaling is objective preserving)
+    hx_keep(VEC(V_X));
     double fl = 0;
     for (int i = lane; i < n; i += 64) fl += 0.5 * X_(i) * HX_(i) + G_(i) * X_(i);
     fval_s = wave_sum(fl);
@@ -1277,7 +1722,7 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
   STAMP(14);
   STAMP_OUT;
   if (tid == 0) {
-    P.fval[b] = have_x ? fval_s : NAN;
+    P.fval[b] = fval_s;
     P.exitflag[b] = flag;
     P.iter[b] = it;
     if (P.polished) P.polished[b] = flag_polished;
@@ -1287,63 +1732,34 @@ template <int T, int NB, int W, int SW, bool RES> __global__ __launch_bounds__(6
 
 }  // namespace
 
-template <int T, int NB, int W, int SW, bool RES> static hipError_t launch_wg(const QpParams& P, int batch, hipStream_t st) {
-  const size_t lds = qp_wg_lds_base_bytes(P.d, W, NB, RES) + (RES ? (size_t)P.d.lds_aw_bytes : 0);
+template <int T, int NB, int W, bool RING> static hipError_t launch_wg(const QpParams& P, int batch, hipStream_t st) {
+  const size_t lds = qp_wg_lds_base_bytes(P.d, W, NB, RING);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_wg_kernel<T, NB, W, SW, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_wg_kernel<T, NB, W, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((qp_wg_kernel<T, NB, W, SW, RES>), dim3(batch), dim3(64 * W), lds, st, P);
+  hipLaunchKernelGGL((qp_wg_kernel<T, NB, W, RING>), dim3(batch), dim3(64 * W), lds, st, P);
   return hipGetLastError();
 }
-// streaming variants by the number of owner-layout slots per wave (W = 8): JT <= 16 -> SW = 2, JT <= 32 -> SW = 4
-template <int T, int NB> static hipError_t launch_stream(const QpParams& P, int batch, hipStream_t st) {
-  const int JT = P.d.J + P.d.JB;
-#ifdef QP_WG_EXPERIMENT   // development only: other workgroup shapes, selected by qp_make_dims from FSAEMPC_WG="W,RES"
-  if (P.d.W == 4) { if (JT <= 8) return launch_wg<T, NB, 4, 2, false>(P, batch, st); if (JT <= 16) return launch_wg<T, NB, 4, 4, false>(P, batch, st); return hipErrorInvalidValue; }
-  if (P.d.W == 2) { if (JT <= 8) return launch_wg<T, NB, 2, 4, false>(P, batch, st); return hipErrorInvalidValue; }
-#endif
-  if (JT <= 16) return launch_wg<T, NB, 8, 2, false>(P, batch, st);
-#ifndef QP_WG_DEV
-  if (T >= 8 && JT <= 24) return launch_wg<T, NB, 8, 3, false>(P, batch, st);   // three slots per wave: 12 fewer doubles of row state per lane
-  if (JT <= 32) return launch_wg<T, NB, 8, 4, false>(P, batch, st);
-#endif
+// the ring variant wherever the LDS budget has room for it (qp_make_dims decides: d.wg_ring); the largest shapes stream from global memory
+template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P, int batch, hipStream_t st) {
+  if (P.d.wg_ring) return launch_wg<T, NB, QP_WG_W, true>(P, batch, st);
+  if constexpr (T >= QP_WG_NORING_MIN_T) return launch_wg<T, NB, QP_WG_W, false>(P, batch, st);
   return hipErrorInvalidValue;
-}
-// resident kernel (when the host reserved LDS for the stream; JT <= 8) followed by the streaming kernel for the leftovers
-template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P0, int batch, hipStream_t st) {
-  QpParams P = P0;
-#ifdef QP_WG_DEV
-  if constexpr (T <= QP_WG_RES_MAX_T) {
-    if (P.d.lds_aw_bytes > 0 && P.d.J + P.d.JB <= 8) {
-      P.only_pending = 0;
-      hipError_t e;
-#ifdef QP_WG_EXPERIMENT
-      if (P.d.W == 4) e = launch_wg<T, NB, 4, 2, true>(P, batch, st); else
-#endif
-      e = launch_wg<T, NB, 8, 1, true>(P, batch, st);
-      if (e != hipSuccess) return e;
-      P.only_pending = 1;
-      return launch_stream<T, NB>(P, batch, st);
-    }
-  }
-#endif
-  P.only_pending = 0;
-  return launch_stream<T, NB>(P, batch, st);
 }
 
 #ifndef QP_WG_TLO
 #define QP_WG_TLO 1
 #define QP_WG_THI 12
 #endif
-// instantiated tile counts of this translation unit: [QP_WG_TLO, QP_WG_THI]; border width 1 only where the headline
-// shapes live (T <= QP_WG_RES_MAX_T), wider borders and 1 elsewhere run the 4-column variant (padded unit columns)
+// instantiated tile counts of this translation unit: [QP_WG_TLO, QP_WG_THI]; border widths 0 and 4 (bordered shapes up to T = 5
+// run on the one-wavefront kernel, qp_solver.hip; from T = 6 on 1..4 border columns run the 4-column variant, padded unit columns)
 template <int T> static hipError_t launch_wg_sel(const QpParams& P, int batch, hipStream_t st) {
   if constexpr (T >= QP_WG_TLO && T <= QP_WG_THI) {
     if (P.d.T == T) {
-#ifdef QP_WG_DEV    // development builds: the bordered headline shapes, every variant
-      if constexpr (T <= QP_WG_RES_MAX_T) { if (P.d.NBk == 1) return launch_wg_T<T, 1>(P, batch, st); }
-      return launch_wg_T<T, 4>(P, batch, st);
-#else               // product: bordered shapes up to T = 5 run on the one-wavefront kernel (qp_solver.hip)
+#ifdef QP_WG_ONLY_NB
+      if (P.d.NBk == QP_WG_ONLY_NB) return launch_wg_T<T, QP_WG_ONLY_NB>(P, batch, st);
+      return hipErrorInvalidValue;
+#else
       if (P.d.NBk == 0) return launch_wg_T<T, 0>(P, batch, st);
       if constexpr (T > 5) return launch_wg_T<T, 4>(P, batch, st);
       return hipErrorInvalidValue;
@@ -1358,5 +1774,8 @@ template <int T> static hipError_t launch_wg_sel(const QpParams& P, int batch, h
 #ifdef QP_WG_ONE_TU
 hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st) { return launch_wg_sel<1>(P, batch, st); }
 #else
-hipError_t QP_WG_CAT(qp_wg_launch_, QP_WG_TLO)(const QpParams& P, int batch, hipStream_t st) { return launch_wg_sel<1>(P, batch, st); }
+#ifndef QP_WG_SYM
+#define QP_WG_SYM QP_WG_TLO
+#endif
+hipError_t QP_WG_CAT(qp_wg_launch_, QP_WG_SYM)(const QpParams& P, int batch, hipStream_t st) { return launch_wg_sel<1>(P, batch, st); }
 #endif

@@ -78,9 +78,11 @@ class LtvBatch:
         return out
 
 
-    def sqp(self, x0, x_ref, x_lin, u_lin, sweeps=3, stream=None):
+    def sqp(self, x0, x_ref, x_lin, u_lin, sweeps=3, stream=None, step=1.0):
         """Re-linearisation (SQP) sweeps of SURVEY 8 f-3: the step is solved, its plan becomes the next linearisation point
-        (what main.m:121-125 does from one MPC period to the next, here within one period), `sweeps` times.  Instances
+        (what main.m:121-125 does from one MPC period to the next, here within one period), `sweeps` times.  `step` < 1 damps
+        the move of the linearisation point, (x_lin, u_lin) += step * (plan - (x_lin, u_lin)): plain re-linearisation (step = 1)
+        has no step control and a bang-bang input may keep flipping between its bounds over a long horizon.  Instances
         whose QP fails keep their previous linearisation point.  Returns the last step's outputs plus `du` = list of
         per-sweep (B,) tensors max|u_opt - u_lin| (how far each sweep still moved)."""
         torch = self.torch
@@ -91,8 +93,8 @@ class LtvBatch:
             out = self.step(x0, x_ref, xl, ul, stream=stream)
             ok = (out["exitflag"] == 0).view(-1, 1)
             du.append(torch.where(ok.view(-1), (out["u_opt"] - ul).abs().amax(1), torch.full((B,), float("nan"), dtype=torch.float64, device=self.device)))
-            xl = torch.where(ok, out["x_opt"], xl).contiguous()
-            ul = torch.where(ok, out["u_opt"], ul).contiguous()
+            xl = torch.where(ok, xl + step * (out["x_opt"] - xl), xl).contiguous()
+            ul = torch.where(ok, ul + step * (out["u_opt"] - ul), ul).contiguous()
         out["du"] = du
         return out
 

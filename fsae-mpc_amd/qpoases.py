@@ -114,57 +114,105 @@ def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=F
     return dict(x=x, fval=fval, exitflag=flag, iter=it, lam=lam, workspace=workspace, kkt=kkt, polished=pol)
 
 
-def qpOASES_sequence(cmd, *args, options=None):
+def qpOASES_sequence(cmd, *args, options=None, aux=False):
     """Mirror of qpOASES_sequence (optimizers/matlab/qpOASES/qpOASES_sequence.m):
-      [QP,x,fval,exitflag,iter,lambda] = qpOASES_sequence('i', H,g,A,lb,ub,lbA,ubA)     (:23)
-      [x,fval,exitflag,iter,lambda]    = qpOASES_sequence('h', QP, g,lb,ub,lbA,ubA)     (:39)
-      [x,fval,exitflag,iter,lambda]    = qpOASES_sequence('m', QP, H,g,A,lb,ub,lbA,ubA) (:51)
-      [x,lambda,workingSetB,workingSetC] = qpOASES_sequence('e', QP, g,lb,ub,lbA,ubA)   (:64)
-                                         qpOASES_sequence('c', QP)                      (:76)
-    The handle owns device copies of H and A, the workspace and the per-call vectors; every call is a cold solve."""
+      [QP,x,fval,exitflag,iter,lambda,auxOutput] = qpOASES_sequence('i', H,g,A,lb,ub,lbA,ubA)     (:23)
+      [QP,x,fval,exitflag,iter,lambda,auxOutput] = qpOASES_sequence('i', H,g,lb,ub)               (:25, bounds-only)
+      [x,fval,exitflag,iter,lambda,auxOutput]    = qpOASES_sequence('h', QP, g,lb,ub,lbA,ubA)     (:39)
+      [x,fval,exitflag,iter,lambda,auxOutput]    = qpOASES_sequence('h', QP, g,lb,ub)             (:41, bounds-only)
+      [x,fval,exitflag,iter,lambda,auxOutput]    = qpOASES_sequence('m', QP, H,g,A,lb,ub,lbA,ubA) (:51)
+      [x,lambda,workingSetB,workingSetC]         = qpOASES_sequence('e', QP, g,lb,ub{,lbA,ubA})   (:64)
+                                                   qpOASES_sequence('c', QP)                      (:76)
+    g, lb, ub, lbA, ubA may carry k columns ((nV, k) / (nC, k) arrays) in 'h' and 'e' -- k QPs sharing the handle's H and A; x
+    and lambda then come back with k columns, fval / exitflag / iter as length-k arrays.  auxOutput (the optional last output of
+    the reference) is appended when aux=True: dict(workingSetB, workingSetC) from the sign of the multipliers (qpOASES.m:58-61).  The handle owns device copies of H and A, the workspace
+    and the per-call vectors; every call is a cold solve."""
     L = lib()
     opts = options if options is not None else default_opts()
     p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
-    f = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
     colmajor = lambda M: np.ascontiguousarray(np.asarray(M, dtype=np.float64).T)
 
-    def outs(nV, nC):
-        return np.zeros(nV), np.zeros(1), np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(nV + nC)
+    def vec(a, rows, k):   # (rows,) or (rows, k) -> k stacked columns (one column is broadcast)
+        if a is None or rows == 0:
+            return None
+        a = np.asarray(a, dtype=np.float64)
+        a = a.reshape(rows, -1) if a.ndim > 1 or a.size != rows else a.reshape(rows, 1)
+        if a.shape[1] not in (1, k):
+            raise ValueError("ERROR (qpOASES): Input dimension mismatch")
+        return np.ascontiguousarray(np.broadcast_to(a, (rows, k)).T)
+
+    def ncols(g, nV):
+        g = np.asarray(g, dtype=np.float64)
+        return g.shape[1] if g.ndim == 2 and g.shape[0] == nV else 1
+
+    def outs(nV, nC, k):
+        return np.zeros((k, nV)), np.zeros(k), np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.int32), np.zeros((k, nV + nC))
+
+    def pack(nV, nC, k, x, fv, fl, it, lam):
+        aux = dict(workingSetB=np.where(lam[:, :nV] > 0, -1, np.where(lam[:, :nV] < 0, 1, 0)).T,
+                   workingSetC=np.where(lam[:, nV:] > 0, -1, np.where(lam[:, nV:] < 0, 1, 0)).T)
+        if k == 1:
+            aux = {k_: v[:, 0] for k_, v in aux.items()}
+            return x[0], float(fv[0]), int(fl[0]), int(it[0]), lam[0], aux
+        return x.T, fv, fl, it, lam.T, aux
 
     if cmd == "i":
-        H, g, A, lb, ub, lbA, ubA = args
-        H = np.asarray(H, dtype=np.float64); A = np.asarray(A, dtype=np.float64).reshape(-1, H.shape[0])
-        nV, nC = H.shape[0], A.shape[0]
-        x, fv, fl, it, lam = outs(nV, nC)
+        if len(args) == 7:
+            H, g, A, lb, ub, lbA, ubA = args
+        elif len(args) == 4:
+            (H, g, lb, ub), A, lbA, ubA = args, None, None, None
+        else:
+            raise ValueError("ERROR (qpOASES): Invalid number of input arguments!")
+        H = np.asarray(H, dtype=np.float64)
+        nV = H.shape[0]
+        A = np.asarray(A, dtype=np.float64).reshape(-1, nV) if A is not None else np.zeros((0, nV))
+        nC = A.shape[0]
+        k = ncols(g, nV)
+        x, fv, fl, it, lam = outs(nV, nC, k)
         h = C.c_int(0)
-        check(L.fsaempc_seq_init(nV, nC, p(colmajor(H)), p(f(g)), p(colmajor(A)), p(f(lb)), p(f(ub)), p(f(lbA)), p(f(ubA)), 1,
-                                 C.byref(opts), C.byref(h), p(x), p(fv), p(fl), p(it), p(lam)), "qpOASES_sequence('i')")
+        check(L.fsaempc_seq_init(nV, nC, p(colmajor(H)), p(vec(g, nV, k)), p(colmajor(A)) if nC else None, p(vec(lb, nV, k)), p(vec(ub, nV, k)),
+                                 p(vec(lbA, nC, k)), p(vec(ubA, nC, k)), k, C.byref(opts), C.byref(h), p(x), p(fv), p(fl), p(it), p(lam)), "qpOASES_sequence('i')")
         _SEQ_DIMS[h.value] = (nV, nC)
-        return h.value, x, float(fv[0]), int(fl[0]), int(it[0]), lam
+        return (h.value,) + pack(nV, nC, k, x, fv, fl, it, lam)[:6 if aux else 5]
     if cmd in ("h", "m"):
         QP = int(args[0])
         nV, nC = _SEQ_DIMS.get(QP, (1, 0))
-        x, fv, fl, it, lam = outs(nV, nC)
         if cmd == "h":
-            g, lb, ub, lbA, ubA = args[1:]
-            rc = L.fsaempc_seq_hotstart(QP, nV, nC, p(f(g)), p(f(lb)), p(f(ub)), p(f(lbA)), p(f(ubA)), 1, C.byref(opts),
-                                        p(x), p(fv), p(fl), p(it), p(lam))
+            if len(args) == 6:
+                g, lb, ub, lbA, ubA = args[1:]
+            elif len(args) == 4:
+                (g, lb, ub), lbA, ubA = args[1:], None, None
+            else:
+                raise ValueError("ERROR (qpOASES): Invalid number of input arguments!")
+            k = ncols(g, nV)
+            x, fv, fl, it, lam = outs(nV, nC, k)
+            rc = L.fsaempc_seq_hotstart(QP, nV, nC, p(vec(g, nV, k)), p(vec(lb, nV, k)), p(vec(ub, nV, k)), p(vec(lbA, nC, k)), p(vec(ubA, nC, k)), k,
+                                        C.byref(opts), p(x), p(fv), p(fl), p(it), p(lam))
         else:
             H, g, A, lb, ub, lbA, ubA = args[1:]
             H = np.asarray(H, dtype=np.float64); A = np.asarray(A, dtype=np.float64).reshape(-1, H.shape[0])
-            rc = L.fsaempc_seq_hotstart_matrices(QP, H.shape[0], A.shape[0], p(colmajor(H)), p(f(g)), p(colmajor(A)), p(f(lb)), p(f(ub)),
-                                                 p(f(lbA)), p(f(ubA)), 1, C.byref(opts), p(x), p(fv), p(fl), p(it), p(lam))
+            nVm, nCm = H.shape[0], A.shape[0]
+            k = ncols(g, nVm)
+            x, fv, fl, it, lam = outs(nVm, nCm, k)
+            rc = L.fsaempc_seq_hotstart_matrices(QP, nVm, nCm, p(colmajor(H)), p(vec(g, nVm, k)), p(colmajor(A)), p(vec(lb, nVm, k)), p(vec(ub, nVm, k)),
+                                                 p(vec(lbA, nCm, k)), p(vec(ubA, nCm, k)), k, C.byref(opts), p(x), p(fv), p(fl), p(it), p(lam))
         check(rc, "qpOASES_sequence('%s')" % cmd)
-        return x, float(fv[0]), int(fl[0]), int(it[0]), lam
+        return pack(nV, nC, k, x, fv, fl, it, lam)[:6 if aux else 5]
     if cmd == "e":
         QP = int(args[0])
         nV, nC = _SEQ_DIMS.get(QP, (1, 0))
-        g, lb, ub, lbA, ubA = args[1:]
-        x, lam = np.zeros(nV), np.zeros(nV + nC)
+        if len(args) == 6:
+            g, lb, ub, lbA, ubA = args[1:]
+        elif len(args) == 4:
+            (g, lb, ub), lbA, ubA = args[1:], None, None
+        else:
+            raise ValueError("ERROR (qpOASES): Invalid number of input arguments!")
+        k = ncols(g, nV)
+        x, lam = np.zeros((k, nV)), np.zeros((k, nV + nC))
         wb, wc = np.zeros(nV, dtype=np.int32), np.zeros(max(nC, 1), dtype=np.int32)
-        check(L.fsaempc_seq_equality(QP, nV, nC, p(f(g)), p(f(lb)), p(f(ub)), p(f(lbA)), p(f(ubA)), 1, C.byref(opts), p(x), p(lam), p(wb), p(wc)),
-              "qpOASES_sequence('e')")
-        return x, lam, wb, wc[:nC]
+        check(L.fsaempc_seq_equality(QP, nV, nC, p(vec(g, nV, k)), p(vec(lb, nV, k)), p(vec(ub, nV, k)), p(vec(lbA, nC, k)), p(vec(ubA, nC, k)), k,
+                                     C.byref(opts), p(x), p(lam), p(wb), p(wc)), "qpOASES_sequence('e')")
+        return (x[0], lam[0], wb, wc[:nC]) if k == 1 else (x.T, lam.T, wb, wc[:nC])
     if cmd == "c":
         check(L.fsaempc_seq_cleanup(int(args[0])), "qpOASES_sequence('c')")
         _SEQ_DIMS.pop(int(args[0]), None)

@@ -120,7 +120,9 @@ int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc,
  * doubles and the results, nothing else.  Every call is a COLD interior-point solve: same results as a qpOASES hot start, but
  * the previous iterate is not used as a starting point (an interior-point method gains little from it).
  * fsaempc_seq_equality is qpOASES_sequence.m:64 ('e'): the equality-constrained QP fixed by the working set of the handle's
- * last 'i'/'h'/'m' solve (first column); it returns FSAEMPC_ERR_SOLVER when that QP has no solution and leaves the handle as is.
+ * last 'i'/'h'/'m' solve (first column; a side is in the set iff its multiplier has the side's sign and exceeds the side's
+ * slack -- on a refined vertex: iff the multiplier is non-zero); it returns FSAEMPC_ERR_SOLVER when that QP has no solution and
+ * leaves the handle as is.
  * Errors mirror the gateway: unknown handle => FSAEMPC_ERR_ARG "Invalid handle to QP instance!", changed
  * dimensions => FSAEMPC_ERR_ARG "QP dimensions must be constant during a sequence!". */
 int fsaempc_seq_init(int nV, int nC, const double* H, const double* g, const double* A,
@@ -258,6 +260,30 @@ int fsaempc_cl_plant_batch_device(int model, int N, double dt, int batch, double
  */
 int fsaempc_cl_accept_batch_device(int model, int N, int batch, const double* x_new, const double* u_new, const int* exitflag,
                                    double* x_keep, double* u_keep, void* stream);
+
+/* ---- track pipeline (host side) --------------------------------------------------- */
+
+/* Spline table of a track as main.m:11-17 produces it: M arc-length segments, xP / yP = M x 4 Bezier control points per axis
+ * (column-major: all P0, then all P1, P2, P3), dl = segment length, L = total length.  Host memory owned by the library
+ * (fsaempc_track_free).  These are the tables fsaempc_spline points at (after a copy to the device). */
+typedef struct {
+  int M;
+  double dl, L;
+  double* xP;
+  double* yP;
+} fsaempc_track;
+
+/* Replaces main.m:11-17: [x,y,...] = read_raceline_csv(file) (util/read_raceline_csv.m:6-19: one header line, columns 1-2 = X, Y),
+ * x_spline = make_spline_periodic(x) (spline/make_spline_periodic.m:9-33), likewise y,
+ * [x_spline,y_spline,dl,L] = arclength_reparam(x_spline,y_spline,M,true) (spline/arclength_reparam.m:15-64; M = 100 in main.m:17).
+ * The reference's quirk in the speed integrand (arclength_reparam.m:20-23) is kept.  Host only, no GPU work. */
+int fsaempc_track_from_csv(const char* path, int M, fsaempc_track* out);
+int fsaempc_track_from_points(const double* x, const double* y, int n, int M, fsaempc_track* out);
+void fsaempc_track_free(fsaempc_track* t);
+/* On-disk table format "FSTRK001" (little endian): 8-byte magic, int32 M, int32 0, double dl, double L, xP (4M doubles), yP (4M). */
+int fsaempc_track_save(const fsaempc_track* t, const char* path);
+int fsaempc_track_load(const char* path, fsaempc_track* out);
+const char* fsaempc_track_last_error(void);
 
 /* ---- diagnostics ---------------------------------------------------------------------------- */
 const char* fsaempc_last_error(void);

@@ -1,7 +1,8 @@
 // mex/qpOASES.cpp -- MEX gateway that makes libfsaempc.so a drop-in for the reference's
-//     [x,fval,exitflag,iter,lambda,auxOutput] = qpOASES(H,g,A,lb,ub,lbA,ubA{,options})
+//     [x,fval,exitflag,iter,lambda,auxOutput] = qpOASES(H,g,A,lb,ub,lbA,ubA{,options{,auxInput}})
 // (optimizers/matlab/qpOASES/qpOASES.m:22-23; bounds-only form :34-35; k-column form :65-67).
-// Not BUILT in this repo (no MATLAB here); type-checked against tests/stub_mex/mex.h by tests/test_abi_cpu.py.
+// Not BUILT in this repo (no MATLAB here); tests/test_abi_cpu.py type-checks it against tests/stub_mex/mex.h and runs it against a
+// functional stand-in of the MEX API and a recording stand-in of libfsaempc (tests/stub_mex/run_gateways.cpp).
 // Build on a MATLAB host:   mex -I<repo>/include mex/qpOASES.cpp -L<repo>/fsae-mpc_amd/lib -lfsaempc
 #include <cmath>
 #include <cstring>
@@ -42,6 +43,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (!mxIsEmpty(prhs[i]) && (!mxIsDouble(prhs[i]) || mxIsComplex(prhs[i]))) mexErrMsgTxt("ERROR (qpOASES): All data has to be provided in double precision!");
   fsaempc_qp_opts opts;
   map_options(nrhs > ndata ? prhs[ndata] : nullptr, &opts);
+  // auxInput (qpOASES.m:23, qpOASES_auxInput.m: initial guess x0 / working set guess): accepted and ignored -- every solve of
+  // this build is a cold interior-point solve followed by an active-set refinement
+  if (nrhs > ndata + 1 && !mxIsEmpty(prhs[ndata + 1])) mexWarnMsgTxt("WARNING (qpOASES): auxInput is ignored (every solve is a cold start)");
   const mxArray *H = prhs[0], *g = prhs[1];
   const mxArray *A = general ? prhs[2] : nullptr, *lb = prhs[general ? 3 : 2], *ub = prhs[general ? 4 : 3];
   const mxArray *lbA = general ? prhs[5] : nullptr, *ubA = general ? prhs[6] : nullptr;

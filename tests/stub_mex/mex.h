@@ -1,6 +1,7 @@
-/* Minimal stand-in for MATLAB's mex.h: declarations only, enough to type-check mex/qpOASES.cpp and mex/qpOASES_sequence.cpp
- * (tests/test_abi_cpu.py::test_mex_gateways_compile runs g++ -fsyntax-only against it).  Written from the documented MEX C API
- * signatures; nothing here is executable and nothing links against it. */
+/* Minimal stand-in for MATLAB's mex.h: the declarations mex/qpOASES.cpp and mex/qpOASES_sequence.cpp use, written from the
+ * documented MEX C API signatures.  tests/test_abi_cpu.py::test_mex_gateways_compile type-checks the gateways against it
+ * (g++ -fsyntax-only); tests/stub_mex/mex_fake.cpp implements these functions on a small in-memory mxArray so that
+ * tests/stub_mex/run_gateways.cpp can RUN the gateways on the CPU against a recording stand-in of libfsaempc. */
 #ifndef FSAEMPC_STUB_MEX_H
 #define FSAEMPC_STUB_MEX_H
 #include <cstddef>
@@ -10,6 +11,7 @@ typedef size_t mwIndex;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 extern "C" {
 void mexErrMsgTxt(const char* msg);
+void mexWarnMsgTxt(const char* msg);
 size_t mxGetM(const mxArray* a);
 size_t mxGetN(const mxArray* a);
 double* mxGetPr(const mxArray* a);

@@ -426,6 +426,61 @@ def test_sequence_equality_call(fm):
     fm.qpOASES_sequence("c", QP)
 
 
+@pytest.mark.parametrize("n,m,polish", [(8, 4, 0), (130, 60, 1), (130, 60, 0)])
+def test_sequence_equality_call_working_set_rule(fm, n, m, polish):
+    """'e' after a solve whose multipliers are NOT a vertex's (refinement switched off: every finite side of an interior-point
+    iterate carries a small non-zero multiplier) and on a shape of the workgroup kernel (n = 130: T = 8).  The working set must
+    follow the rule "multiplier has the side's sign and exceeds the side's slack" (include/fsaempc.h), not the sign alone: the
+    returned set is compared with that rule evaluated in numpy on the returned (x, lambda), and x of 'e' with a dense KKT solve."""
+    rng = np.random.default_rng(100 + n + polish)
+    Q = rng.normal(size=(n, n)); H = Q @ Q.T / n + np.eye(n); g = rng.normal(size=n) * 3
+    A = rng.normal(size=(m, n)) / np.sqrt(n)
+    lb, ub = -0.3 * np.ones(n), 0.3 * np.ones(n)
+    lbA, ubA = -0.2 * np.ones(m), 0.2 * np.ones(m)
+    opts = fm.default_opts(polish=polish)
+    QP, x, f, fl, it, lam = fm.qpOASES_sequence("i", H, g, A, lb, ub, lbA, ubA, options=opts)
+    assert fl == 0
+    v = np.concatenate([x, A @ x]); lo = np.concatenate([lb, lbA]); hi = np.concatenate([ub, ubA])
+    ws = np.where((lam > 0) & (lam > np.abs(v - lo)), -1, np.where((lam < 0) & (-lam > np.abs(hi - v)), 1, 0))
+    assert 2 <= (ws != 0).sum() < n + m                       # some sides active, not all of them
+    if polish == 0:
+        assert (lam != 0).sum() > (ws != 0).sum()             # the sign alone would have put more sides into the set
+    g2 = g * 1.01
+    xe, lame, wb, wc = fm.qpOASES_sequence("e", QP, g2, lb, ub, lbA, ubA, options=opts)
+    assert np.array_equal(wb, ws[:n]) and np.array_equal(wc, ws[n:])
+    G = np.vstack([np.eye(n), A])
+    act = np.nonzero(ws)[0]
+    Aw = G[act]; rhs = np.where(ws[act] < 0, lo[act], hi[act]); k = len(act)
+    K = np.block([[H, Aw.T], [Aw, np.zeros((k, k))]])
+    sol = np.linalg.lstsq(K, np.concatenate([-g2, rhs]), rcond=None)[0]
+    assert np.abs(xe - sol[:n]).max() <= 1e-6 * max(1.0, np.abs(sol[:n]).max())
+    fm.qpOASES_sequence("c", QP)
+
+
+def test_sequence_bounds_only_and_k_columns(fm):
+    """The remaining call forms of qpOASES_sequence.m through the mirror: bounds-only 'i' / 'h' (:25-26, :41-42) and k columns in
+    'h' (k QPs sharing the handle's H and A), against the one-shot entry."""
+    rng = np.random.default_rng(3)
+    n, m = 12, 5
+    Q = rng.normal(size=(n, n)); H = Q @ Q.T + np.eye(n); g = rng.normal(size=n) * 2
+    A = rng.normal(size=(m, n)); lb, ub = -0.5 * np.ones(n), 0.5 * np.ones(n); lbA, ubA = -0.4 * np.ones(m), 0.4 * np.ones(m)
+    QP, x, f, fl, it, lam = fm.qpOASES_sequence("i", H, g, lb, ub)                 # bounds-only
+    xr, fr, flr, _, _, _ = fm.qpOASES(H, g, lb, ub)
+    assert fl == 0 and np.abs(x - xr).max() <= 1e-8 and lam.shape == (n,)
+    x2, f2, fl2, it2, lam2 = fm.qpOASES_sequence("h", QP, 1.1 * g, lb, ub)
+    assert fl2 == 0 and np.abs(x2 - fm.qpOASES(H, 1.1 * g, lb, ub)[0]).max() <= 1e-8
+    fm.qpOASES_sequence("c", QP)
+    QP, x, f, fl, it, lam, aux = fm.qpOASES_sequence("i", H, g, A, lb, ub, lbA, ubA, aux=True)
+    assert fl == 0 and aux["workingSetB"].shape == (n,) and aux["workingSetC"].shape == (m,)
+    G2 = np.stack([g, 0.5 * g, -g], axis=1)                                          # three columns
+    X, F, FL, IT, LAM = fm.qpOASES_sequence("h", QP, G2, lb, ub, lbA, ubA)
+    assert X.shape == (n, 3) and LAM.shape == (n + m, 3) and (FL == 0).all()
+    for j in range(3):
+        xj = fm.qpOASES(H, G2[:, j], A, lb, ub, lbA, ubA)[0]
+        assert np.abs(X[:, j] - xj).max() <= 1e-7
+    fm.qpOASES_sequence("c", QP)
+
+
 def test_edge_cases(fm, torch_):
     torch = torch_
     # nV = 1, nC = 0 ; empty batch ; random SPD data up to nV = 196 (FSAEMPC_MAX_NV: 12 tiles + 4 border columns) ; ragged tile sizes
@@ -595,18 +650,18 @@ def test_closed_loop_monte_carlo_abnormal_exits(fm, torch_, model):
 @pytest.mark.parametrize("model,N", [(0, 20), (1, 20), (1, 80)])
 def test_sqp_sweeps(fm, torch_, orc, model, N):
     """Re-linearisation sweeps ((1, 80) is BASELINE configs[4]: dynamic N = 80, nV = 164, nC = 1600) against
-    the same loop through the oracle; the sweeps contract."""
+    the same loop through the oracle.  N <= 20: three plain sweeps contract.  N = 80: plain re-linearisation has no step control
+    (the reference has no SQP at all) and a bang-bang acceleration keeps flipping over the 4 s horizon; with damped steps
+    (step = 0.5) and eight sweeps at least half of the instances settle (measured with the oracle loop: 3 of 4), and those are
+    compared."""
     torch = torch_
     tr = fm.Track.load("fsg2019"); otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
-    B, K = (6, 3) if N <= 20 else (4, 3)
+    B, K, step = (6, 3, 1.0) if N <= 20 else (4, 8, 0.5)
     x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 31, range(B))
-    out = fm.LtvBatch(model, N, 0.05, tr, B).sqp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul), sweeps=K)
+    out = fm.LtvBatch(model, N, 0.05, tr, B).sqp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul), sweeps=K, step=step)
     torch.cuda.synchronize()
     assert (out["exitflag"].cpu().numpy() == 0).all()
     du = np.stack([d.cpu().numpy() for d in out["du"]])
-    # plain re-linearisation has no step control (the reference has no SQP at all): at N = 20 most instances contract, a
-    # bang-bang one may keep flipping an input between its bounds; over the 4 s horizon of N = 80 the sweeps of these
-    # synthetic starts do not settle within three sweeps, so only the parity with the oracle loop is checked there
     if N <= 20:
         assert np.median(du[-1] / du[0]) <= 0.5, du
     checked = 0
@@ -616,12 +671,12 @@ def test_sqp_sweeps(fm, torch_, orc, model, N):
             u_prev = ulb
             u, xo, sl, f, fl, it = orc.ltv_step(model, otr, N, 0.05, x0[b], xr[b].T, xlb, ulb)
             assert fl == 0
-            xlb, ulb = xo.reshape(N, -1).T, u.reshape(N, 2).T
-        if np.abs(ulb - u_prev).max() > 1.0:
+            xlb, ulb = xlb + step * (xo.reshape(N, -1).T - xlb), ulb + step * (u.reshape(N, 2).T - ulb)
+        if np.abs(u.reshape(N, 2).T - u_prev).max() > 1.0:
             continue                                   # still moving by more than 1: not a converged comparison point
         checked += 1
         assert np.max(np.abs(out["u_opt"][b].cpu().numpy() - u)) <= 1e-3 * max(1.0, np.abs(u).max()), b
-    assert checked >= (B // 2 if N <= 20 else 0)
+    assert checked >= B // 2, (checked, du)
 
 
 def test_shipped_build_matches_O1_build(fm, tmp_path):

@@ -64,7 +64,7 @@ def test_defect_is_flagged_and_repaired(tmp_path):
     p = tmp_path / "bad.s"
     p.write_text(BAD)
     hits = chk.scan(str(p))
-    assert len(hits) == 1 and hits[0][1] == ".LBB0_3" and "v_accvgpr_write_b32 a52, v48" in hits[0][4][0][1]
+    assert len(hits) == 1 and hits[0][1] == ".LBB0_3" and "v_accvgpr_write_b32 a52, v48" in hits[0][4][0][1] and chk.safe_to_move(hits[0])
     chk.repair(str(p), hits)
     fixed = [ln.strip() for ln in p.read_text().split("\n") if ln.strip()]
     i = fixed.index(".LBB0_3:")
@@ -82,6 +82,38 @@ def test_spill_code_counts_as_allocator_made(tmp_path):
     p = tmp_path / "spill.s"
     p.write_text(BAD.replace("v_accvgpr_write_b32 a52, v48", "scratch_load_dword v2, off, off offset:64"))
     assert len(chk.scan(str(p))) == 1
+
+
+def _run_fix(path):
+    import subprocess, sys
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa_exec_prologue.py"), "--fix", str(path)], capture_output=True, text=True)
+
+
+def test_only_the_proven_pattern_is_repaired_automatically(tmp_path):
+    """--fix moves plain v_accvgpr_write copies that sit directly ahead of the restore and nothing else.  A spill reload (its
+    s_waitcnt would be crossed), an s_waitcnt in the prologue, another vector instruction in the prologue (it could consume the
+    moved copy's result, or run under the stale mask itself) or two copies into the same AGPR stop the build with exit code 2 and
+    leave the file untouched."""
+    ok = tmp_path / "ok.s"
+    ok.write_text(BAD)
+    r = _run_fix(ok)
+    assert r.returncode == 0 and "moved behind it" in r.stdout and chk.scan(str(ok)) == []
+    two = tmp_path / "two.s"
+    two.write_text(BAD.replace("\tv_accvgpr_write_b32 a52, v48\n", "\tv_accvgpr_write_b32 a52, v48\n\tv_accvgpr_write_b32 a53, v49\n"))
+    assert _run_fix(two).returncode == 0 and chk.scan(str(two)) == []
+    cases = {
+        "scratch_load": BAD.replace("v_accvgpr_write_b32 a52, v48", "scratch_load_dword v2, off, off offset:64"),
+        "waitcnt": BAD.replace("\tv_accvgpr_write_b32 a52, v48\n", "\ts_waitcnt vmcnt(0)\n\tv_accvgpr_write_b32 a52, v48\n"),
+        "consumer": BAD.replace("\tv_accvgpr_write_b32 a52, v48\n", "\tv_accvgpr_write_b32 a52, v48\n\tv_accvgpr_read_b32 v7, a52\n"),
+        "other_valu": BAD.replace("\tv_accvgpr_write_b32 a52, v48\n", "\tv_accvgpr_write_b32 a52, v48\n\tv_add_f64 v[8:9], v[8:9], v[10:11]\n"),
+        "same_dest": BAD.replace("\tv_accvgpr_write_b32 a52, v48\n", "\tv_accvgpr_write_b32 a52, v48\n\tv_accvgpr_write_b32 a52, v49\n"),
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".s")
+        p.write_text(text)
+        r = _run_fix(p)
+        assert r.returncode == 2 and "NOT the proven pattern" in r.stdout, (name, r.returncode, r.stdout)
+        assert p.read_text() == text, name                      # untouched
 
 
 def test_reports_of_the_built_library():

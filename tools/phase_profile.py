@@ -14,7 +14,7 @@ import torch  # noqa: E402
 import fsae_mpc_amd as fm  # noqa: E402
 
 NAMES_V1 = ["setup", "row1", "hx", "syrk", "resid+toLDS", "chol", "solve2", "passAv2", "row2", "passAtw", "solve1", "passAv1", "row3+update", "epilogue"]
-NAMES_WG = ["setup", "row1", "hx", "acc_init+syrk", "resid+rhs", "diag add+dmax", "chol (K loop)", "border+backward", "pass2 (fused)", "row2", "corrector solve", "pass3", "row3a+alpha", "update sweep", "epilogue"]
+NAMES_WG = ["setup", "row1", "hx", "acc_init+syrk", "resid+rhs", "diag add+dmax", "chol (K loop)", "border+backward", "pass2 (fused)", "row2", "corrector solve", "pass3", "row3a+alpha", "update sweep", "epilogue + refinement", "(of syrk: per-trip wait + barrier)"]
 NAMES = NAMES_V1 if os.environ.get("FSAEMPC_QP_V1") else NAMES_WG
 
 
