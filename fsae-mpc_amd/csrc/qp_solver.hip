@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   int* cnt_sh = perm_sh + 16 * ntr;                                  // [T+1] class counts / starts ; then tcs [ntr], aoff [ntr+1]
   int* tcs_sh = cnt_sh + 16;
   int* aoff_sh = tcs_sh + ntr;
+  int* chc_sh = aoff_sh + ntr + 1;                                   // [ceil(m/64)][16] rows of each class per 64-row chunk, then their starts
+  double* Fr_sh = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(chc_sh + ((m + 63) >> 6) * 16) + 7) & ~(uintptr_t)7);   // [m] row scale of every original row
 
   // ---- column scaling E_j = 1/sqrt(H_jj), or 1/max|A_:j| where H_jj ~ 0 (slack columns) ----
   for (int j = tid; j < np; j += 256) {
@@ -184,26 +186,56 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
                  // reference's MEX gateway rejects such a call; a device entry cannot look at the data before the launch)
   for (int j = tid; j < np; j += 256) { const int uj = j < n ? U(j) : -1; const double gj = uj >= 0 ? g[uj] : 0.0; Es[j] = Esh[j]; gw[j] = gj * Esh[j]; bad |= !(fabs(gj) < INFINITY); }
 
-  // ---- row order: class = last core column tile with a nonzero; stable counting sort by class ----
+  // ---- one pass over A, thread = row (coalesced: consecutive threads read consecutive rows of a column, the loads of a thread are
+  //      independent): row scaling F_r = 1 / max_j |A[r][j] E_j| and the row's class = last core column tile with a nonzero.
+  //      (Round 2 scanned every row twice with dependent / uncoalesced loads and ranked the rows with an O(m^2) loop: 14 ms of
+  //      the 200 ms of a dynamic N = 60 batch.) ----
+  __syncthreads();   // Esh complete
+  const int ncols = nc < n ? nc : n;
+  const int nchunk = (m + 63) >> 6;
+  for (int i = tid; i < nchunk * 16; i += 256) chc_sh[i] = 0;
   if (tid < 16) cnt_sh[tid] = 0;
   __syncthreads();
-  const int ncols = nc < n ? nc : n;
-  for (int r = tid; r < m; r += 256) {
+  for (int r0 = 0; r0 < m; r0 += 256) {
+    const int r = r0 + tid;
     int e = 0;
-    for (int col = ncols - 1; col >= 0; --col)
-      if (Aat(r, col) != 0.0) { e = col >> 4; break; }
-    cls_sh[r] = e;
-    atomicAdd(&cnt_sh[e], 1);
+    double rm = 0.0;
+    if (r < m) {
+      for (int col = 0; col < n; ++col) {
+        const double a = fabs(Aat(r, col));
+        rm = fmax(rm, a * Esh[col]);
+        if (a != 0.0 && col < ncols) e = col >> 4;
+      }
+      cls_sh[r] = e;
+      Fr_sh[r] = rm > 1e-12 ? 1.0 / rm : 1.0;
+    }
+    // stable counting sort by class, part 1: rows of each class in this 64-row chunk (the lanes of a wave hold consecutive rows)
+    for (int cl = 0; cl < T; ++cl) {
+      const unsigned long long mk = __ballot(r < m && e == cl);
+      if (lane == 0 && r0 + 64 * w < m) chc_sh[((r0 >> 6) + w) * 16 + cl] = __popcll(mk);
+    }
   }
   __syncthreads();
-  if (tid == 0) { int run = 0; for (int e = 0; e < T; ++e) { const int cn = cnt_sh[e]; cnt_sh[e] = run; run += cn; } }
+  if (tid < T) {   // per class: running start of every chunk (after the total of the lower classes is known: two steps)
+    int tot = 0;
+    for (int ch = 0; ch < nchunk; ++ch) tot += chc_sh[ch * 16 + tid];
+    cnt_sh[tid] = tot;
+  }
+  __syncthreads();
+  if (tid < T) {
+    int start = 0;
+    for (int cl = 0; cl < tid; ++cl) start += cnt_sh[cl];
+    for (int ch = 0; ch < nchunk; ++ch) { const int cn = chc_sh[ch * 16 + tid]; chc_sh[ch * 16 + tid] = start; start += cn; }
+  }
   for (int p = tid; p < 16 * ntr; p += 256) perm_sh[p] = -1;
   __syncthreads();
-  for (int r = tid; r < m; r += 256) {
-    const int e = cls_sh[r];
-    int rank = 0;
-    for (int r2 = 0; r2 < r; ++r2) rank += (cls_sh[r2] == e);
-    perm_sh[cnt_sh[e] + rank] = r;
+  for (int r0 = 0; r0 < m; r0 += 256) {   // part 2: position = start of (chunk, class) + rank among the chunk's earlier rows of the class
+    const int r = r0 + tid;
+    const int e = r < m ? cls_sh[r] : -1;
+    for (int cl = 0; cl < T; ++cl) {
+      const unsigned long long mk = __ballot(e == cl);
+      if (e == cl) perm_sh[chc_sh[((r0 >> 6) + w) * 16 + cl] + __popcll(mk & ((1ull << lane) - 1ull))] = r;
+    }
   }
   __syncthreads();
   // tiles per trip (16 sorted positions), stream offsets, phase ends
@@ -227,10 +259,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     const int s = 16 * js + c, pp = 4 * s + q;
     const int r = (s < 4 * ntr) ? perm_sh[pp] : -1;
     const bool valid = r >= 0;
-    double rm = 0;
-    if (valid)
-      for (int j = 0; j < n; ++j) rm = fmax(rm, fabs(Aat(r, j)) * Esh[j]);
-    double f = (valid && rm > 1e-12) ? 1.0 / rm : (valid ? 1.0 : 0.0);
+    const double f = valid ? Fr_sh[r] : 0.0;
     Fs[js * 64 + lane] = f;
     perm_g[js * 64 + lane] = r;
     for (int bb = 0; bb < 4; ++bb)
@@ -2286,7 +2315,8 @@ void qp_make_dims(int n, int m, QpDims* d) {
   }
   d->prep_tw = 16;
   for (;;) {
-    d->lds_prep = ((size_t)d->np + 4 + (size_t)d->prep_tw * (4 * d->Kq + 1)) * sizeof(double) + ((size_t)4 * d->Kq + 16 * (size_t)d->ntr + 16 + 2 * (size_t)d->ntr + 1 + 3) * sizeof(int);
+    d->lds_prep = ((size_t)d->np + 4 + (size_t)d->prep_tw * (4 * d->Kq + 1) + (size_t)m + 2) * sizeof(double) +
+                  ((size_t)4 * d->Kq + 16 * (size_t)d->ntr + 16 + 2 * (size_t)d->ntr + 1 + (size_t)((m + 63) / 64) * 16 + 6) * sizeof(int);
     if (d->lds_prep <= 96 * 1024 || d->prep_tw == 2) break;   // keep the staging tile small enough for more than one workgroup per CU
     d->prep_tw >>= 1;
   }

@@ -38,6 +38,11 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define AINL __attribute__((always_inline))
 
 extern __shared__ __attribute__((aligned(16))) double slds[];
+// Lanes of ONE wave exchanging data through LDS: the hardware keeps a wave's DS operations in order, so no s_barrier is needed, but
+// the compiler must be told -- from a single thread's point of view a location another lane writes never changes, and load
+// elimination / PRE across a predicated store hands lanes their own stale value (seen: the last block of the single-wave forward
+// solve, right in lane group 0 and wrong in groups 1..3).  Every such hand-off gets this fence.
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 namespace {
 
@@ -197,8 +202,8 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
   const double* __restrict__ Awg = ws + d.off_Aw;
   const double* __restrict__ Hw = ws + d.off_Hw;
   const int* __restrict__ perm = reinterpret_cast<const int*>(ws + d.off_meta);
-  const int* __restrict__ tcs = perm + (size_t)(d.J > 0 ? d.J : 1) * 64;
-  const int* __restrict__ aoff = tcs + d.ntr;
+  const int* __restrict__ tcs_g = perm + (size_t)(d.J > 0 ? d.J : 1) * 64;
+  const int* __restrict__ aoff_g = tcs_g + d.ntr;
   const double* __restrict__ Abg = ws + d.off_Ab;
   auto rowarr = [&](int a) AINL -> double* { return ws + d.off_rows + (size_t)a * d.rowlen; };
   double* aL = rowarr(R_L); double* aU = rowarr(R_U);
@@ -222,6 +227,13 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
   constexpr int oUbb = oC1 + 2 * C1S;          // NB x NB factor of the border Schur complement
   constexpr int oRing = oUbb + 16;             // pass 1 (RING): two chunks of 2T operand records (1 KiB each); outside pass 1
   constexpr int oP2 = oRing;                   //   (and without RING: W*np doubles) W more partial n-vectors (refinement)
+  constexpr int oMeta = oRing + (RING ? 2 * 2 * T * 128 : W * np);   // stream directory (ints): tcs[ntr], aoff[ntr + 1]
+  // The directory of the operand stream in LDS: every pair of k-steps of every pass looks its trip up, and from global memory
+  // each lookup was a full round trip in front of the operand loads that depend on it (seen in the ISA of pass 1: a
+  // global_load_dword + s_waitcnt vmcnt(0) at the top of every trip).
+  int* tcs = reinterpret_cast<int*>(&slds[oMeta]);
+  int* aoff = tcs + ntr;
+  for (int i = tid; i < 2 * ntr + 1; i += NTH) tcs[i] = tcs_g[i];   // (tcs and aoff are contiguous in the workspace too)
   static_assert(T * 256 >= W * (16 * T + 16), "H~ z partials alias the panel buffer");
   static_assert(!RING || 2 * 2 * T * 128 >= W * (16 * T + 16), "the second set of partials aliases the ring");
   static_assert((oRing % 2) == 0 && (oC1 % 2) == 0 && (oCw % 2) == 0, "16-byte aligned LDS arrays");
@@ -398,7 +410,9 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 #pragma unroll
     for (int f = 0; f < NBB; ++f) pbv[f] = 0.0;
     for (int js = w; js < J; js += W) {
+      WAVE_SYNC();
       CWS_(0, lane) = src(js * 64 + lane);
+      WAVE_SYNC();
       slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
         const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
         const v2d wv = *reinterpret_cast<const v2d*>(&CWS_(0, q * 16 + (s0 & 15)));
@@ -431,6 +445,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
   auto hx_tiles = [&](int oZ, auto keep_tag) AINL {
     constexpr bool KEEP = decltype(keep_tag)::value;
     for (int i = lane; i < np; i += 64) slds[oPB + w * np + i] = 0.0;
+    WAVE_SYNC();
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       v4d h = {0.0, 0.0, 0.0, 0.0};
@@ -447,10 +462,12 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
           if (c == 0) slds[oPB + w * np + 16 * I + q + 4 * p] += rs;
           colsum = fma(h[p], slds[oZ + 16 * I + q + 4 * p], colsum);
         }
+        WAVE_SYNC();   // (lanes c == 0 and lanes q == 0 read-modify-write the same partial vector)
         if (I != Jt) {
           colsum = q_sum(colsum);                                            // column 16J + c of H_IJ' z_I
           if (q == 0) slds[oPB + w * np + 16 * Jt + c] += colsum;
         }
+        WAVE_SYNC();
       }
       if (!KEEP) acc[t] = h;
     }
@@ -598,13 +615,26 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
     return z;
   };
   // U'y = b in place on the LDS vector at oV (core part), right-looking: y_K = U_KK^-T b_K (+ one step of refinement against U_KK),
-  // then b_J -= U_KJ' y_K for J > K.  Called by one wave.
+  // then b_J -= U_KJ' y_K for J > K.  Called by one wave.  The tiles of block row K+1 (the first PFN of them) are requested before
+  // step K's arithmetic: a step is a dependent chain of reductions, and with the loads issued behind the previous step's fence
+  // every step waited a full L2 / Infinity-Cache round trip for its tiles (measured: 3.6 k cycles per step, ~0.8 k of it arithmetic).
+  constexpr int PFN = T <= 8 ? T : 5;
   auto vec_fwd = [&](int oV) AINL {
+    v4d pf[PFN];                                                                       // pf[j] = tile (K, K + j) of the coming step
+#pragma unroll
+    for (int j = 0; j < PFN; ++j) if (j < T) pf[j] = utile(0, j);
 #pragma unroll
     for (int K = 0; K < T; ++K) {
+      v4d row[PFN];
+#pragma unroll
+      for (int j = 0; j < PFN; ++j) row[j] = pf[j];
+      if (K + 1 < T) {
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) if (K + 1 + j < T) pf[j] = utile(K + 1, K + 1 + j);
+      }
       const double tk = slds[oV + 16 * K + c];
       const v4d Yt = tile_load17(oYL + K * 272);                                      // U_KK^-T
-      const v4d Ukk = utile(K, K);
+      const v4d Ukk = row[0];
       double y[4];
 #pragma unroll
       for (int p = 0; p < 4; ++p) y[p] = grp16_sum(Yt[p] * tk);                       // y_K[q+4p] = sum_c Y[q+4p][c] t[c]
@@ -616,32 +646,45 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 #pragma unroll
         for (int p = 0; p < 4; ++p) y[p] += grp16_sum(Yt[p] * r);
       }
+      WAVE_SYNC();                                                                     // every lane has read its t[c] of block K
       if (c == 0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) slds[oV + 16 * K + q + 4 * p] = y[p];
       }
 #pragma unroll
       for (int Jt = K + 1; Jt < T; ++Jt) {
-        const v4d Ukj = utile(K, Jt);
+        const v4d Ukj = (Jt - K < PFN) ? row[(Jt - K) < PFN ? (Jt - K) : 0] : utile(K, Jt);
         double sj = 0.0;
 #pragma unroll
         for (int p = 0; p < 4; ++p) sj = fma(Ukj[p], y[p], sj);                        // this lane group's rows of (U_KJ' y_K)[c]
         sj = q_sum(sj);
         if (q == 0) slds[oV + 16 * Jt + c] -= sj;
       }
+      WAVE_SYNC();                                                                     // lane group 0's updates are what block K+1 reads
     }
   };
-  // U x = y in place: x_K = U_KK^-1 (y_K - sum_{J>K} U_KJ x_J) (+ one step of refinement).  Called by one wave.
+  // U x = y in place: x_K = U_KK^-1 (y_K - sum_{J>K} U_KJ x_J) (+ one step of refinement).  Called by one wave.  Same prefetch.
   auto vec_bwd = [&](int oV) AINL {
     double x[T];
+    v4d pf[PFN];
+#pragma unroll
+    for (int j = 0; j < PFN; ++j) if (T - 1 + j < T) pf[j] = utile(T - 1, T - 1 + j);
+    WAVE_SYNC();
 #pragma unroll
     for (int K = T - 1; K >= 0; --K) {
+      v4d row[PFN];
+#pragma unroll
+      for (int j = 0; j < PFN; ++j) row[j] = pf[j];
+      if (K > 0) {
+#pragma unroll
+        for (int j = 0; j < PFN; ++j) if (K - 1 + j < T) pf[j] = utile(K - 1, K - 1 + j);
+      }
       const v4d Yt = tile_load17(oYL + K * 272);
-      const v4d Ukk = utile(K, K);
+      const v4d Ukk = row[0];
       double sp[4] = {0.0, 0.0, 0.0, 0.0}, wv[4];
 #pragma unroll
       for (int Jt = K + 1; Jt < T; ++Jt) {
-        const v4d Ukj = utile(K, Jt);
+        const v4d Ukj = (Jt - K < PFN) ? row[(Jt - K) < PFN ? (Jt - K) : 0] : utile(K, Jt);
 #pragma unroll
         for (int p = 0; p < 4; ++p) sp[p] = fma(Ukj[p], x[Jt], sp[p]);                 // this lane's column of (U_KJ x_J)[q+4p]
       }
@@ -658,14 +701,17 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         for (int p = 0; p < 4; ++p) dcor = fma(Yt[p], wv[p] - grp16_sum(Ukk[p] * x[K]), dcor);
         x[K] += q_sum(dcor);
       }
+      WAVE_SYNC();                                                                     // every lane has read its y[q+4p] of block K
       if (q == 0) slds[oV + 16 * K + c] = x[K];
     }
+    WAVE_SYNC();
   };
   // border part of a solve (the last wave does it; the factor of the border block is in LDS): R holds y_c = U^-T b_c (core) and b_b
   // (border); leaves the border solution in R[nc+e] and y_c - sum_e u_e x_e in the core.  Caller syncs.
   auto border_solve = [&](int oR) AINL {
     if (NB > 0 && w == W - 1) {
       double yb[NBB], xb[NBB];
+      WAVE_SYNC();
 #pragma unroll
       for (int e = 0; e < NB; ++e) {
         double dsum = 0.0;
@@ -682,6 +728,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         for (int f = e + 1; f < NB; ++f) tt -= UBB_(e, f) * xb[f];
         xb[e] = tt / UBB_(e, e);
       }
+      WAVE_SYNC();
       for (int i = lane; i < nc; i += 64) {
         double r = slds[oR + i];
 #pragma unroll
@@ -692,6 +739,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 #pragma unroll
         for (int e = 0; e < NB; ++e) slds[oR + nc + e] = xb[e];
       }
+      WAVE_SYNC();
     }
   };
 
@@ -815,6 +863,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 #pragma unroll
             for (int f = e; f < NB; ++f) UBB_(e, f) = Ub[e][f];
         }
+        WAVE_SYNC();
         if (with_rhs) { border_solve(VEC(V_R1)); border_solve(VEC(V_R2)); }
       }
       red_put(0, (double)fb2);
@@ -1197,8 +1246,10 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
             const Row r = ld_row(ix);
             const bool hl = r.l > -INFINITY, hu = r.u < INFINITY;
             const double dl = hl ? r.zl / r.tl : 0.0, du = hu ? r.zu / r.tu : 0.0;
-            CWS_(0, lane) = hl ? r.v - r.l - r.tl : 0.0; CWS_(1, lane) = dl; CWS_(2, lane) = hl ? dl / r.tl : 0.0;
+            WAVE_SYNC();
             CWS_(3, lane) = hu ? r.u - r.v - r.tu : 0.0; CWS_(4, lane) = du; CWS_(5, lane) = hu ? du / r.tu : 0.0;
+            CWS_(0, lane) = hl ? r.v - r.l - r.tl : 0.0; CWS_(1, lane) = dl; CWS_(2, lane) = hl ? dl / r.tl : 0.0;
+            WAVE_SYNC();
           }
           double ka = 0.0, kc = 0.0;
           slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
@@ -1443,7 +1494,9 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
       for (int f = 0; f < NBB; ++f) { vb[f] = NB ? slds[oV + nc + f] : 0.0; pcb[f] = 0.0; pdb[f] = 0.0; }
       for (int js = w; js < J; js += W) {
         const int ix = js * 64 + lane;
+        WAVE_SYNC();
         CWS_(0, lane) = PA[ix]; CWS_(1, lane) = mode == 0 ? PB[ix] : 0.0; CWS_(2, lane) = mode == 0 ? PY[ix] : 0.0;
+        WAVE_SYNC();
         double kq = 0.0, ky = 0.0;
         slot_pairs(js, [&](const v2d (&bq)[T], int s0) AINL {
           const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15), cix = q * 16 + (s0 & 15);
