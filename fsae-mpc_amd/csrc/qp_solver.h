@@ -61,7 +61,9 @@ int qp_selftest_mfma(char* msg, int msglen);
 // operand ring of pass 1.  Mirrors the carve at the top of qp_wg_kernel.
 #define QP_WG_NVEC_FIXED 14   /* X G HX P1 P2 P3 DX E R1 R2 + DV W1V W2V LV */
 inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk, bool ring) {
+  const size_t part2 = (size_t)W * d.np;                                        // second set of partial n-vectors ...
+  const size_t extra = (ring && (size_t)240 * d.T > part2) ? (size_t)240 * d.T : part2;   // ... or the tail of the three-chunk operand ring laid over U_KK^-T tiles + panel buffer + these
   return ((size_t)(QP_WG_NVEC_FIXED + 2 * NBk) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + 256 + (size_t)W * 96 +
-          (size_t)2 * 8 * W + (size_t)W * 6 * 64 + (size_t)2 * (4 + NBk) * 16 + 16 + (ring ? (size_t)2 * 2 * d.T * 128 : (size_t)W * d.np) + (size_t)(d.ntr + 2)) * sizeof(double);   // last term: the stream directory (2 ntr + 1 ints)
+          (size_t)2 * 8 * W + (size_t)W * 6 * 64 + (size_t)3 * (16 + 256) + 16 + extra + (size_t)(3 * d.ntr / 2 + 2)) * sizeof(double);   // last term: the stream directory (3 ntr + 1 ints)
 }
 

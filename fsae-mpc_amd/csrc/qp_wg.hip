@@ -214,29 +214,35 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
   double* aVA = rowarr(R_VA); double* aVC = rowarr(R_VC); double* aWC = rowarr(R_RPL);   // G dx_aff, G dx_cen (then G dx), G dx_cor
 
   // ---- LDS carve (offsets in doubles; host mirror: qp_wg_lds_base_bytes in qp_solver.h) ----
-  constexpr int oYL = V_NARR * np;             // T tiles U_KK^-T, row-major, 17-double rows
-  constexpr int oPB = oYL + T * 272;           // T panel-row tiles in register image [p][lane]; outside the factorisation:
-                                               //   W partial n-vectors of H~ z (T*256 >= W*np for every T)
-  constexpr int oWP = oPB;                     // W partial n-vectors of A'w products: same region (never live together with the above)
-  constexpr int oUK = oPB + T * 256;           // register image of the diagonal factor tile U_KK of the current block step
+  constexpr int oUK = V_NARR * np;             // register image of the diagonal factor tile U_KK of the current block step
   constexpr int oScr = oUK + 256;              // per-wave scratch [6][16]
   constexpr int oRed = oScr + W * 96;          // reduction scratch: 2 buffers x 8 values x W
   constexpr int oCw = oRed + 2 * 8 * W;        // per-wave coefficient stage of the slot passes: [wave][6 arrays][64]
-  constexpr int oC1 = oCw + W * 6 * 64;        // pass 1: per-trip row weights, two buffers of [4 arrays + NB border columns of A~][16]
-  constexpr int C1S = (4 + NB) * 16;
-  constexpr int oUbb = oC1 + 2 * C1S;          // NB x NB factor of the border Schur complement
-  constexpr int oRing = oUbb + 16;             // pass 1 (RING): two chunks of 2T operand records (1 KiB each); outside pass 1
-  constexpr int oP2 = oRing;                   //   (and without RING: W*np doubles) W more partial n-vectors (refinement)
-  constexpr int oMeta = oRing + (RING ? 2 * 2 * T * 128 : W * np);   // stream directory (ints): tcs[ntr], aoff[ntr + 1]
+  constexpr int oC1 = oCw + W * 6 * 64;        // pass 1: per-trip row weights and side operand, three buffers of C1S
+  constexpr int C1S = 16 + 256;                // per buffer: D[16] (row q*4 + k-step), then the side operand S[pair][q][16 columns][2 k-steps]
+  constexpr int oUbb = oC1 + 3 * C1S;          // NB x NB factor of the border Schur complement
+  constexpr int oYL = oUbb + 16;               // T tiles U_KK^-T, row-major, 17-double rows
+  constexpr int oPB = oYL + T * 272;           // T panel-row tiles in register image [p][lane]; outside the factorisation:
+                                               //   W partial n-vectors of H~ z (T*256 >= W*np for every T)
+  constexpr int oWP = oPB;                     // W partial n-vectors of A'w products: same region (never live together with the above)
+  constexpr int oP2 = oPB + T * 256;           // W more partial n-vectors (refinement)
+  constexpr int XS_ = (RING && 240 * T > W * np) ? 240 * T : W * np;
+  // pass 1 (RING): three chunks of 2T operand records (1 KiB each) = 768 T doubles laid over U_KK^-T tiles, panel buffer and the
+  // second partials (272 T + 256 T + >= 240 T, contiguous).  Every pass 1 is followed by a factorisation that rewrites the first
+  // two, and the partial vectors are dead across it.
+  constexpr int oRing = oYL;
+  constexpr int oMeta = oP2 + XS_;             // stream directory (ints): tcs[ntr], aoff[ntr + 1], rend[ntr]
   // The directory of the operand stream in LDS: every pair of k-steps of every pass looks its trip up, and from global memory
   // each lookup was a full round trip in front of the operand loads that depend on it (seen in the ISA of pass 1: a
-  // global_load_dword + s_waitcnt vmcnt(0) at the top of every trip).
+  // global_load_dword + s_waitcnt vmcnt(0) at the top of every trip).  rend[tr] = end of the run of trips with tr's tile count.
   int* tcs = reinterpret_cast<int*>(&slds[oMeta]);
   int* aoff = tcs + ntr;
+  int* rend = aoff + ntr + 1;
   for (int i = tid; i < 2 * ntr + 1; i += NTH) tcs[i] = tcs_g[i];   // (tcs and aoff are contiguous in the workspace too)
+  for (int i = tid; i < ntr; i += NTH) { const int t0 = tcs_g[i]; int e = i + 1; while (e < ntr && tcs_g[e] == t0) ++e; rend[i] = e; }
+  for (int i = tid; i < 3 * C1S; i += NTH) slds[oC1 + i] = 0.0;     // unused columns of the side operand of pass 1 stay zero
   static_assert(T * 256 >= W * (16 * T + 16), "H~ z partials alias the panel buffer");
-  static_assert(!RING || 2 * 2 * T * 128 >= W * (16 * T + 16), "the second set of partials aliases the ring");
-  static_assert((oRing % 2) == 0 && (oC1 % 2) == 0 && (oCw % 2) == 0, "16-byte aligned LDS arrays");
+  static_assert((oRing % 2) == 0 && (oC1 % 2) == 0 && (oCw % 2) == 0 && (oMeta % 2) == 0, "16-byte aligned LDS arrays");
 #define VEC(a) ((a) * np)
 #define X_(i) slds[VEC(V_X) + (i)]
 #define G_(i) slds[VEC(V_G) + (i)]
@@ -948,10 +954,13 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         }
     };
     if constexpr (RING) {
-      // Workgroup-shared operand ring: chunk = one trip (2 pairs x tc records).  Per trip: every wave waits for its own
-      // outstanding DMAs / stage loads, the stage of the trip's row weights is committed, ONE barrier (chunk `tr` has landed
-      // for everybody, everybody is done reading chunk `tr-1`), then the DMAs of trip tr+1 are issued into the other chunk
-      // and fly during the matrix-core work of trip tr.
+      // Workgroup-shared operand ring of THREE chunks (chunk = one trip = 2 pairs x tc records).  At the barrier of trip t every
+      // wave has waited for its own DMAs of chunk t+1 (issued one whole trip earlier) and committed the stage of trip t+1, so
+      // behind the barrier chunks t and t+1 are complete for everybody and everybody is done reading chunk t-1, which the DMAs
+      // of trip t+2 then overwrite.  The operands of the first pair of trip t+1 can therefore be read while trip t is still in
+      // the matrix cores: the LDS reads of one pair always fly under the MFMAs of the pair before, across trip boundaries too.
+      // (With two chunks and the reads of a trip issued behind its barrier, nothing overlapped: doubling the MFMAs, the tile
+      // reads or the side reads each added their full cost, profiles/round3/pass1_ablation.txt.)
       auto issue = [&](int tr, int chunk) AINL {
         const int nrec = 2 * tcs[tr];
         const char* g0 = reinterpret_cast<const char*>(Awg + (size_t)aoff[tr] * 128);
@@ -959,86 +968,136 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (size_t)r * 1024 + lane * 16),
                                            (__attribute__((address_space(3))) void*)(&slds[oRing + (chunk * 2 * T + r) * 128]), 16, 0, 0);
       };
-      // stage of the trip's 16 rows x (4 weights + NB border columns): lane a*16 + e of the staging wave(s) holds array a, entry e
-      // (e = lane group * 4 + k-step of the trip)
+      // stage of the trip's 16 rows: lane a*16 + e of the staging wave(s) holds array a, entry e (e = lane group q * 4 + k-step of
+      // the trip).  Wave W-1: D, W1, W2, W3; wave W-2: D * border column a.  D goes to the broadcast array the matrix tiles scale
+      // their A operand with; the others become columns of the SIDE OPERAND S (16 rows x 16 columns, columns 0..2 = w1..w3,
+      // 3..3+NB = D * border columns, the rest stays zero), laid out as the B operand of one matrix-core instruction per pair:
+      // A~_ct' S gives A~'w1..w3 and the border column of A~'DA~ for column tile ct in one accumulator tile.
       auto stage_load = [&](int tr, double (&reg)[2]) AINL {
         const int s = 4 * tr, js = s >> 4, e = lane & 15;
         const int ix = js * 64 + (e >> 2) * 16 + (s & 15) + (e & 3);
-        const int a = lane >> 4;   // wave W-1: arrays 0..3 (D, W1, W2, W3); wave W-2: border columns 0..3
+        const int a = lane >> 4;
         reg[0] = reg[1] = 0.0;
         if (w == W - 1) reg[0] = (a == 0 ? aD : (a == 1 ? aW1 : (a == 2 ? aW2 : aW3)))[ix];
-        if (NB > 0 && w == W - 2 && a < NB) reg[1] = Abg[(size_t)a * JS + ix];
+        if (NB > 0 && w == W - 2 && a < NB) reg[1] = aD[ix] * Abg[(size_t)a * JS + ix];
       };
       auto stage_commit = [&](int buf, const double (&reg)[2]) AINL {
-        if (w == W - 1) slds[oC1 + buf * C1S + lane] = reg[0];
-        if (NB > 0 && w == W - 2 && (lane >> 4) < NB) slds[oC1 + buf * C1S + 64 + lane] = reg[1];
+        const int e = lane & 15, a = lane >> 4, qq = e >> 2, kk = e & 3;
+        const int si = oC1 + buf * C1S + 16 + (((kk >> 1) * 4 + qq) * 16) * 2 + (kk & 1);   // S[pair kk/2][qq][column][kk & 1]
+        if (w == W - 1) { if (a == 0) slds[oC1 + buf * C1S + e] = reg[0]; else slds[si + (a - 1) * 2] = reg[0]; }
+        if (NB > 0 && w == W - 2 && a < NB) slds[si + (3 + a) * 2] = reg[1];
       };
       double sreg[2] = {0.0, 0.0};
-      if (ntr > 0) { issue(0, 0); stage_load(0, sreg); }
-      for (int tr = 0; tr < ntr; ++tr) {
-        const int ch = tr & 1;
+      v4d sacc[CW];
+#pragma unroll
+      for (int ci = 0; ci < CW; ++ci) sacc[ci] = (v4d){0.0, 0.0, 0.0, 0.0};
+      if (ntr > 0) {
+        issue(0, 0); stage_load(0, sreg);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_commit(0, sreg);
+        if (ntr > 1) { issue(1, 1); stage_load(1, sreg); }
+      }
+      int ch = 0;                       // chunk / stage buffer of the current trip (tr mod 3)
+      // the barrier of trip t (see above); afterwards the DMAs and stage loads of trip t+2 are under way
+      auto sync_trip = [&](int t, int cht) AINL {
 #if QP_STAMPS
         const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
 #endif
+        const int c1 = cht == 2 ? 0 : cht + 1, c2 = c1 == 2 ? 0 : c1 + 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stage_commit(ch, sreg);
+        if (t + 1 < ntr) stage_commit(c1, sreg);
         __syncthreads();
 #if QP_STAMPS
         st_acc[15] += __builtin_amdgcn_s_memtime() - tw0_;   // diagnostic build: share of pass 1 spent in the per-trip wait + barrier
 #endif
-        if (tr + 1 < ntr) { issue(tr + 1, ch ^ 1); stage_load(tr + 1, sreg); }
+        if (t + 2 < ntr) { issue(t + 2, c2); stage_load(t + 2, sreg); }
         asm volatile("" ::: "memory");
-        const int tc = tcs[tr];
-        // My active tiles of this trip are a PREFIX of my tile list (tiles are dealt in column-major order, so tJ[t] grows with t):
-        // their count selects a straight-line body -- every LDS read of the pair issued up front, then the multiplies, then the
-        // matrix-core instructions back to back, no per-tile branches and waits.
-        int nact = 0;
+      };
+      // One run of trips with the same tile count tc.  My active tiles of such a trip are a PREFIX of my tile list (tiles are dealt
+      // in column-major order, so tJ[t] grows with t): their count K selects a straight-line body without per-tile branches.
+      auto run_k = [&](auto Kc, int tr0, int tr1, int tc) AINL {
+        constexpr int K = decltype(Kc)::value;
+        constexpr int KK = K > 0 ? K : 1;
+        constexpr bool PIPE = K <= 5;     // (more tiles: two pairs of operands in registers next to the accumulators would spill)
+        struct POps { v2d dd, sv, bi[KK], bj[KK], bc[CW]; };
+        auto ld = [&](int chk, int u, POps& o) AINL {
+          const int rb = oRing + (chk * 2 * T + u * tc) * 128 + lane * 2;
+          o.dd = *reinterpret_cast<const v2d*>(&slds[oC1 + chk * C1S + q * 4 + 2 * u]);
+          o.sv = *reinterpret_cast<const v2d*>(&slds[oC1 + chk * C1S + 16 + u * 128 + lane * 2]);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) nact += (tJ[t] < tc) ? 1 : 0;
-        auto pair_k = [&](auto Kc, int u) AINL {
-          constexpr int K = decltype(Kc)::value;
-          constexpr int KK = K > 0 ? K : 1;
-          const int cq = oC1 + ch * C1S + q * 4 + 2 * u;
-          const int rb = oRing + (ch * 2 * T + u * tc) * 128 + lane * 2;
-          v2d bi[KK], bj[KK], bc[CW], ab[NBB];
-          const v2d dd = *reinterpret_cast<const v2d*>(&slds[cq]), w1 = *reinterpret_cast<const v2d*>(&slds[cq + 16]);
-          const v2d w2 = *reinterpret_cast<const v2d*>(&slds[cq + 32]), w3 = *reinterpret_cast<const v2d*>(&slds[cq + 48]);
+          for (int t = 0; t < K; ++t) { o.bi[t] = *reinterpret_cast<const v2d*>(&slds[rb + tI[t] * 128]); o.bj[t] = *reinterpret_cast<const v2d*>(&slds[rb + tJ[t] * 128]); }
 #pragma unroll
-          for (int t = 0; t < K; ++t) { bi[t] = *reinterpret_cast<const v2d*>(&slds[rb + tI[t] * 128]); bj[t] = *reinterpret_cast<const v2d*>(&slds[rb + tJ[t] * 128]); }
-#pragma unroll
-          for (int ci = 0; ci < CW; ++ci) { const int ct = w + W * ci; bc[ci] = *reinterpret_cast<const v2d*>(&slds[rb + (ct < tc ? ct : 0) * 128]); }
-#pragma unroll
-          for (int e = 0; e < NB; ++e) ab[e] = *reinterpret_cast<const v2d*>(&slds[cq + 64 + 16 * e]);
+          for (int ci = 0; ci < CW; ++ci) { const int ct = w + W * ci; o.bc[ci] = *reinterpret_cast<const v2d*>(&slds[rb + (ct < tc ? ct : 0) * 128]); }
+        };
+        auto mm = [&](const POps& o) AINL {
 #pragma unroll
           for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int t = 0; t < K; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[h] * bi[t][h], bj[t][h], acc[t], 0, 0, 0);
-          // VALU side products for my column tiles
+            for (int t = 0; t < K; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.dd[h] * o.bi[t][h], o.bj[t][h], acc[t], 0, 0, 0);
+          // side products of my column tiles: A~_ct' S
 #pragma unroll
-          for (int ci = 0; ci < CW; ++ci) {
-            const double act = (w + W * ci < tc) ? 1.0 : 0.0;
+          for (int ci = 0; ci < CW; ++ci)
+            if (w + W * ci < tc) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const double bch = act * bc[ci][h];
-              p1[ci] = fma(w1[h], bch, p1[ci]); p2[ci] = fma(w2[h], bch, p2[ci]); p3[ci] = fma(w3[h], bch, p3[ci]);
-#pragma unroll
-              for (int e = 0; e < NB; ++e) pb[e][ci] = fma(dd[h] * ab[e][h], bch, pb[e][ci]);
+              for (int h = 0; h < 2; ++h) sacc[ci] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.bc[ci][h], o.sv[h], sacc[ci], 0, 0, 0);
             }
-          }
         };
-        auto trip_k = [&](auto Kc) AINL { pair_k(Kc, 0); pair_k(Kc, 1); };
+        POps A, B;
+        sync_trip(tr0, ch);
+        ld(ch, 0, A);
+        for (int t = tr0;;) {
+          const int chn = ch == 2 ? 0 : ch + 1;
+          const bool more = t + 1 < tr1;
+          if constexpr (PIPE) {
+            ld(ch, 1, B);
+            mm(A);
+            if (more) ld(chn, 0, A);     // chunk and stage of trip t+1 are complete since the barrier of trip t
+            mm(B);
+          } else {
+            mm(A);
+            ld(ch, 1, A);
+            mm(A);
+            if (more) ld(chn, 0, A);
+          }
+          ch = chn;
+          if (!more) break;
+          ++t;
+          sync_trip(t, ch);
+        }
+      };
+      for (int tr = 0; tr < ntr;) {
+        const int tc = tcs[tr], tr1 = rend[tr];
+        int nact = 0;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) nact += (tJ[t] < tc) ? 1 : 0;
         switch (nact) {
-          case 0: trip_k(IC<0>{}); break;
-          case 1: trip_k(IC<1>{}); break;
-          case 2: if constexpr (NTW >= 2) trip_k(IC<2>{}); break;
-          case 3: if constexpr (NTW >= 3) trip_k(IC<3>{}); break;
-          case 4: if constexpr (NTW >= 4) trip_k(IC<4>{}); break;
-          case 5: if constexpr (NTW >= 5) trip_k(IC<5>{}); break;
-          case 6: if constexpr (NTW >= 6) trip_k(IC<6>{}); break;
-          case 7: if constexpr (NTW >= 7) trip_k(IC<7>{}); break;
-          case 8: if constexpr (NTW >= 8) trip_k(IC<8>{}); break;
-          case 9: if constexpr (NTW >= 9) trip_k(IC<9>{}); break;
-          default: if constexpr (NTW >= 10) trip_k(IC<10>{}); break;
+          case 0: run_k(IC<0>{}, tr, tr1, tc); break;
+          case 1: run_k(IC<1>{}, tr, tr1, tc); break;
+          case 2: if constexpr (NTW >= 2) run_k(IC<2>{}, tr, tr1, tc); break;
+          case 3: if constexpr (NTW >= 3) run_k(IC<3>{}, tr, tr1, tc); break;
+          case 4: if constexpr (NTW >= 4) run_k(IC<4>{}, tr, tr1, tc); break;
+          case 5: if constexpr (NTW >= 5) run_k(IC<5>{}, tr, tr1, tc); break;
+          case 6: if constexpr (NTW >= 6) run_k(IC<6>{}, tr, tr1, tc); break;
+          case 7: if constexpr (NTW >= 7) run_k(IC<7>{}, tr, tr1, tc); break;
+          case 8: if constexpr (NTW >= 8) run_k(IC<8>{}, tr, tr1, tc); break;
+          case 9: if constexpr (NTW >= 9) run_k(IC<9>{}, tr, tr1, tc); break;
+          default: if constexpr (NTW >= 10) run_k(IC<10>{}, tr, tr1, tc); break;
+        }
+        tr = tr1;
+      }
+      // accumulator tile of column tile ct: lane (q, c), register p = entry 16 ct + q + 4 p of side column c
+#pragma unroll
+      for (int ci = 0; ci < CW; ++ci) {
+        const int ct = w + W * ci;
+        if (ct < T) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int i = 16 * ct + q + 4 * p;
+            if (c == 0) P1_(i) = sacc[ci][p];
+            else if (c == 1) P2_(i) = sacc[ci][p];
+            else if (c == 2) P3_(i) = sacc[ci][p];
+            else if (c < 3 + NB) MB_(c - 3, i) = sacc[ci][p];
+          }
         }
       }
       __syncthreads();   // the ring region is reused (second set of partial n-vectors) once everybody is through the last chunk
@@ -1069,6 +1128,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
       }
       if (NB > 0) __syncthreads();   // the border sums of every wave are in the scratch
     }
+    if constexpr (!RING)
 #pragma unroll
     for (int ci = 0; ci < CW; ++ci) {
       const int ct = w + W * ci;
@@ -1080,14 +1140,22 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
       }
     }
     if constexpr (NB > 0) {
-      if (w == W - 1 && lane == 0) {   // the border sums of the sweep at the top (the pass's barriers lie in between)
+      constexpr int NSUM = NB * (NB + 1) / 2 + 3 * NB;
+      if (w == W - 1 && lane < NSUM) {   // the border sums of the sweep at the top (the pass's barriers lie in between): one lane per sum
+        double t_ = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) t_ += slds[oScr + ww * 96 + lane];
         int k_ = 0;
+#pragma unroll
         for (int e = 0; e < NB; ++e)
-          for (int f = e; f < NB; ++f) { double t_ = 0.0; for (int ww = 0; ww < W; ++ww) t_ += slds[oScr + ww * 96 + k_]; MB_(e, nc + f) = t_; MB_(f, nc + e) = t_; ++k_; }
+#pragma unroll
+          for (int f = e; f < NB; ++f) { if (k_ == lane) { MB_(e, nc + f) = t_; MB_(f, nc + e) = t_; } ++k_; }
+#pragma unroll
         for (int e = 0; e < NB; ++e) {
-          double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-          for (int ww = 0; ww < W; ++ww) { t1 += slds[oScr + ww * 96 + k_]; t2 += slds[oScr + ww * 96 + k_ + 1]; t3 += slds[oScr + ww * 96 + k_ + 2]; }
-          P1_(nc + e) = t1; P2_(nc + e) = t2; P3_(nc + e) = t3; k_ += 3;
+          if (k_ == lane) P1_(nc + e) = t_;
+          if (k_ + 1 == lane) P2_(nc + e) = t_;
+          if (k_ + 2 == lane) P3_(nc + e) = t_;
+          k_ += 3;
         }
       }
     }
