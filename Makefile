@@ -23,11 +23,14 @@ $(LIBDIR)/qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsa
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_TU=$*
 
-# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 1..12) is compiled once per range of tile counts (lo_hi)
+# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 1..12) is compiled once per range of tile counts (lo_hi).
+# WGFLAGS: without machine LICM and with sinking-to-avoid-spills the T = 8 kernel spills 8 VGPRs instead of 166 (256 are its budget
+# at two waves per SIMD): hoisted address arithmetic no longer lives across the whole iteration loop.
+WGFLAGS := -mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1
 WGOBJ := $(LIBDIR)/qp_wg_1_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_7_8.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
 $(LIBDIR)/qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
-	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
+	$(CC_CHECKED) $@ $< $(HIPFLAGS) $(WGFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
 
 # host-side track pipeline (no device code)
 $(LIBDIR)/track.o: $(CSRC)/track.cpp include/fsaempc.h
@@ -38,9 +41,9 @@ COMMON := $(LIBDIR)/ltv_build.o $(LIBDIR)/reference.o $(LIBDIR)/plant.o $(LIBDIR
 $(LIBDIR)/libfsaempc.so: $(QPOBJ) $(WGOBJ) $(COMMON)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-# development builds of the workgroup kernel: ONE instantiation (T = 8, no border: BASELINE configs[2], dynamic N = 60) linked with the
+# development builds of the workgroup kernel: ONE instantiation (T = 8 + slack border: BASELINE configs[2], dynamic N = 60) linked with the
 # shipped objects of everything else; plain and with phase stamps.  Select with FSAEMPC_LIB.
-WGDEVFLAGS := -DQP_WG_TLO=8 -DQP_WG_THI=8 -DQP_WG_SYM=7 -DQP_WG_ONLY_NB=0
+WGDEVFLAGS := $(WGFLAGS) -DQP_WG_TLO=8 -DQP_WG_THI=8 -DQP_WG_SYM=7 -DQP_WG_ONLY_NB=4
 $(LIBDIR)/wgdev_qp_wg.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(WGDEVFLAGS) -c $< -o $@
@@ -58,7 +61,7 @@ $(LIBDIR)/libfsaempc_wgdevst.so: $(LIBDIR)/wgdevst_qp_wg.o $(WGDEVREST)
 DBGOBJ := $(LIBDIR)/dbg_qp_solver_tu0.o $(LIBDIR)/dbg_qp_solver_tu1.o $(LIBDIR)/dbg_qp_solver_tu2.o $(LIBDIR)/dbg_qp_wg_1_5.o
 $(LIBDIR)/dbg_qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
-	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_DEBUG_DUMP -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
+	$(CC_CHECKED) $@ $< $(HIPFLAGS) $(WGFLAGS) -DQP_DEBUG_DUMP -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
 $(LIBDIR)/dbg_qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_DEBUG_DUMP -DQP_TU=$*

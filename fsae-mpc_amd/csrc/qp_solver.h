@@ -7,7 +7,6 @@
 #ifndef QP_WG_W
 #define QP_WG_W 8                 // wavefronts per QP of the workgroup kernel
 #endif
-#define QP_WG_NORING_MIN_T 11   // tile counts from which qp_wg.hip also builds the variant without the LDS operand ring (T = 12 with a border does not have the room)
 // an iterate on which the factorisation breaks down gets one try at the active-set refinement if it is this close to primal
 // feasibility and complementarity (both kernels and the oracle: ltv_oracle_qp.c)
 #define QP_BREAKDOWN_TRY_TOL 1e-4
@@ -31,7 +30,7 @@ struct QpDims {
   size_t lds_solve, lds_prep;                                                  // in bytes
   int W;                  // wavefronts per QP of the workgroup solve kernel (qp_wg.hip)
   int NBk;                // border width of the workgroup kernel's variant: 0 or 4
-  size_t wg_ring;         // workgroup kernel: != 0 if pass 1 reads the operand stream through the LDS ring (the LDS budget has room for it)
+  size_t wg_ring;         // (reserved; always 1: pass 1 of the workgroup kernel reads the operand stream through its LDS ring for every shape)
   size_t lds_wg;          // total dynamic LDS of the workgroup solve kernel
   size_t off_U;           // workgroup kernel: the Cholesky factor's tiles as register images [tile][4][64] (read by the solving wave), in doubles
 };
@@ -57,12 +56,12 @@ __host__ __device__ inline int qp_solver_index(const QpDims& d, int u) { const i
 bool qp_runs_wavefront_kernel(const QpDims& d);   // kernel selection of qp_launch
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid = nullptr);
 int qp_selftest_mfma(char* msg, int msglen);
-// LDS bytes of the workgroup solve kernel (qp_wg.hip); NBk = border width of the kernel variant (0 or 4), ring = with the
-// operand ring of pass 1.  Mirrors the carve at the top of qp_wg_kernel.
+// LDS bytes of the workgroup solve kernel (qp_wg.hip); NBk = border width of the kernel variant (0 or 4).  Mirrors the carve at
+// the top of qp_wg_kernel.
 #define QP_WG_NVEC_FIXED 14   /* X G HX P1 P2 P3 DX E R1 R2 + DV W1V W2V LV */
-inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk, bool ring) {
+inline size_t qp_wg_lds_base_bytes(const QpDims& d, int W, int NBk) {
   const size_t part2 = (size_t)W * d.np;                                        // second set of partial n-vectors ...
-  const size_t extra = (ring && (size_t)240 * d.T > part2) ? (size_t)240 * d.T : part2;   // ... or the tail of the three-chunk operand ring laid over U_KK^-T tiles + panel buffer + these
+  const size_t extra = (size_t)240 * d.T > part2 ? (size_t)240 * d.T : part2;   // ... or the tail of the three-chunk operand ring laid over U_KK^-T tiles + panel buffer + these
   return ((size_t)(QP_WG_NVEC_FIXED + 2 * NBk) * d.np + (size_t)d.T * 272 + (size_t)d.T * 256 + 256 + (size_t)W * 96 +
           (size_t)2 * 8 * W + (size_t)W * 6 * 64 + (size_t)3 * (16 + 256) + 16 + extra + (size_t)(3 * d.ntr / 2 + 2)) * sizeof(double);   // last term: the stream directory (3 ntr + 1 ints)
 }

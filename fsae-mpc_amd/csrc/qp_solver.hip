@@ -2304,14 +2304,11 @@ void qp_make_dims(int n, int m, QpDims* d) {
   {
     d->lds_solve = ((size_t)(V_NARR + (d->NB ? d->NB : 1)) * d->np + (size_t)d->T * 272 + (size_t)(3 * d->T) * 128 + (size_t)(6 + d->NB) * 64) * sizeof(double);   // ring = StreamCfg<T>::R = 3T records
   }
-  {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP; its pass 1 reads the operand stream through an LDS ring
-      // wherever the 160 KiB budget has room for it (everything but T = 12 with a border)
+  {   // workgroup solve kernel (qp_wg.hip), W = 8 wavefronts per QP
     d->W = QP_WG_W;
     d->NBk = d->nb == 0 ? 0 : 4;
-    const size_t with_ring = qp_wg_lds_base_bytes(*d, d->W, d->NBk, true);
-    d->wg_ring = (with_ring <= 160 * 1024 || d->T < QP_WG_NORING_MIN_T) ? 1 : 0;
-    if (const char* ex = getenv("FSAEMPC_WG_RING")) { if (ex[0] == '0' && d->T >= QP_WG_NORING_MIN_T) d->wg_ring = 0; }   // A/B runs
-    d->lds_wg = qp_wg_lds_base_bytes(*d, d->W, d->NBk, d->wg_ring != 0);
+    d->wg_ring = 1;
+    d->lds_wg = qp_wg_lds_base_bytes(*d, d->W, d->NBk);
   }
   d->prep_tw = 16;
   for (;;) {

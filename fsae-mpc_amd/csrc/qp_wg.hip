@@ -160,11 +160,18 @@ DEVINL int diag_factor(int c, int q, v4d& Ud, v4d& Yk, double floor_abs) {
 #define QP_STAMPS 0
 #endif
 #if QP_STAMPS   // diagnostic build only: cycles of wave 0 per phase (barrier waits included), written to P.dump[b*16 + phase]
-#define STAMP_DECL unsigned long long st_acc[16]; for (int i_ = 0; i_ < 16; ++i_) st_acc[i_] = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#define STAMP_DECL unsigned long long st_xs[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_acc[16]; for (int i_ = 0; i_ < 16; ++i_) st_acc[i_] = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #define STAMP(id) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[id] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#if QP_STAMPS == 2   // slots 8..15 instead: per wave, cycles from the end of pass 1 to the arrival at the factorisation's first barrier
+#define STAMP_OUT do { if (P.dump && P.dump_stage == 9 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) { P.dump[(size_t)b * 16 + i_] = (double)st_acc[i_]; P.dump[(size_t)b * 16 + 8 + i_] = (double)st_xs[i_]; } } } while (0)
+#define XCAP(k) do { __builtin_amdgcn_sched_barrier(0); st_xs[k] += __builtin_amdgcn_s_memtime() - st_t0; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define STAMP_OUT do { if (P.dump && P.dump_stage == 9 && tid == 0) for (int i_ = 0; i_ < 16; ++i_) P.dump[(size_t)b * 16 + i_] = (double)st_acc[i_]; } while (0)
+#define XCAP(k) do { } while (0)
+#endif
 #else
 #define STAMP_DECL
+#define XCAP(k) do { } while (0)
 #define STAMP(id) do { } while (0)
 #define STAMP_OUT do { } while (0)
 #endif
@@ -180,10 +187,9 @@ struct TagKeep { static constexpr bool value = true; };
 struct TagInit { static constexpr bool value = false; };
 
 // ---------------------------------------------------------------------------------------------
-// solve kernel: T column tiles of 16, NB border columns (0 or 4), W wavefronts per QP, RING = pass 1 reads the operand
-// stream through the workgroup-shared LDS ring (else straight from global memory: shapes whose LDS budget has no room for it)
+// solve kernel: T column tiles of 16, NB border columns (0 or 4), W wavefronts per QP
 // ---------------------------------------------------------------------------------------------
-template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 : 1) void qp_wg_kernel(QpParams P) {
+template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 : 1) void qp_wg_kernel(QpParams P) {
   constexpr int NT = T * (T + 1) / 2;
   constexpr int NTW = (NT + W - 1) / W;         // accumulator tiles per wave
   constexpr int CW = (T + W - 1) / W;           // column tiles per wave (A'w products of pass 1)
@@ -226,8 +232,8 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
                                                //   W partial n-vectors of H~ z (T*256 >= W*np for every T)
   constexpr int oWP = oPB;                     // W partial n-vectors of A'w products: same region (never live together with the above)
   constexpr int oP2 = oPB + T * 256;           // W more partial n-vectors (refinement)
-  constexpr int XS_ = (RING && 240 * T > W * np) ? 240 * T : W * np;
-  // pass 1 (RING): three chunks of 2T operand records (1 KiB each) = 768 T doubles laid over U_KK^-T tiles, panel buffer and the
+  constexpr int XS_ = 240 * T > W * np ? 240 * T : W * np;
+  // pass 1: three chunks of 2T operand records (1 KiB each) = 768 T doubles laid over U_KK^-T tiles, panel buffer and the
   // second partials (272 T + 256 T + >= 240 T, contiguous).  Every pass 1 is followed by a factorisation that rewrites the first
   // two, and the partial vectors are dead across it.
   constexpr int oRing = oYL;
@@ -764,6 +770,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         for (int p = 0; p < 4; ++p)
           if (mine && p == (c >> 2)) { acc[t][p] += dadd; dmax_l = fmax(dmax_l, acc[t][p]); }
       }
+    XCAP(3);
     if (NB > 0) {
       for (int i = tid; i < np; i += NTH) {
 #pragma unroll
@@ -774,6 +781,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         }
       }
     }
+    XCAP(5);
     red_put(0, wave_max(dmax_l));
     __syncthreads();
     const double dmax = red_max(0);
@@ -899,13 +907,6 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
   // the VALU beside them.  Per-row weights from the row arrays D, W1, W2, W3.  Writes P1..P3 and MB (border column / block
   // of A'DA) directly (one owner per entry).
   auto pass_syrk = [&]() AINL {
-    double p1[CW], p2[CW], p3[CW], pb[NBB][CW];
-#pragma unroll
-    for (int ci = 0; ci < CW; ++ci) {
-      p1[ci] = p2[ci] = p3[ci] = 0.0;
-#pragma unroll
-      for (int e = 0; e < NBB; ++e) pb[e][ci] = 0.0;
-    }
     if constexpr (NB > 0) {
       // border block of A'DA and border entries of A'w1..w3: sums over ALL rows of products of per-row numbers only -- a sweep over
       // my slots (owner lanes), one wave reduction per sum, partials into the per-wave scratch (summed behind the pass's barriers)
@@ -931,41 +932,22 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 #pragma unroll
       for (int k_ = 0; k_ < NSUM; ++k_) { const double t_ = wave_sum(sm[k_]); if (lane == 0) slds[oScr + w * 96 + k_] = t_; }
     }
-    struct PairOps { v2d bi[NTW], bj[NTW], bc[CW], dd, w1, w2, w3, ab[NBB]; int tc; };
-    auto do_pair = [&](const PairOps& o) AINL {
-      const int tc = o.tc;
-#pragma unroll
-      for (int t = 0; t < NTW; ++t)
-        if (tJ[t] < tc) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.dd[h] * o.bi[t][h], o.bj[t][h], acc[t], 0, 0, 0);
-        }
-      // VALU side products for my column tiles (and the border scalars on the last wave)
-#pragma unroll
-      for (int ci = 0; ci < CW; ++ci)
-        if (w + W * ci < tc) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const double bch = o.bc[ci][h];
-            p1[ci] = fma(o.w1[h], bch, p1[ci]); p2[ci] = fma(o.w2[h], bch, p2[ci]); p3[ci] = fma(o.w3[h], bch, p3[ci]);
-#pragma unroll
-            for (int e = 0; e < NB; ++e) pb[e][ci] = fma(o.dd[h] * o.ab[e][h], bch, pb[e][ci]);
-          }
-        }
-    };
-    if constexpr (RING) {
-      // Workgroup-shared operand ring of THREE chunks (chunk = one trip = 2 pairs x tc records).  At the barrier of trip t every
-      // wave has waited for its own DMAs of chunk t+1 (issued one whole trip earlier) and committed the stage of trip t+1, so
-      // behind the barrier chunks t and t+1 are complete for everybody and everybody is done reading chunk t-1, which the DMAs
-      // of trip t+2 then overwrite.  The operands of the first pair of trip t+1 can therefore be read while trip t is still in
-      // the matrix cores: the LDS reads of one pair always fly under the MFMAs of the pair before, across trip boundaries too.
-      // (With two chunks and the reads of a trip issued behind its barrier, nothing overlapped: doubling the MFMAs, the tile
-      // reads or the side reads each added their full cost, profiles/round3/pass1_ablation.txt.)
+    {
+      // Lane and wave id are re-made at the places that use them (two v_mbcnt / one s_mov, opaque to the compiler), and the stream
+      // directory is read into scalar registers: the kernel-wide `lane` and `w` have the longest live ranges of the kernel, so they
+      // are what the register allocator spills -- and a scratch reload inside the trip loop is a vector-memory operation BEHIND the
+      // DMAs just issued: waiting for it (vmcnt) waits for the DMAs too, which exposes the very latency the ring hides (seen in the
+      // ISA: a reload + s_waitcnt vmcnt(0) in front of every global_load_lds of the issue loop).
+      auto lane_now = [&]() AINL -> int { int l_; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_)); return l_; };
+      int w_r;
+      asm volatile("s_mov_b32 %0, %1" : "=s"(w_r) : "s"(w));
+      auto sload = [&](const int* p_) AINL -> int { return __builtin_amdgcn_readfirstlane(*p_); };
       auto issue = [&](int tr, int chunk) AINL {
-        const int nrec = 2 * tcs[tr];
-        const char* g0 = reinterpret_cast<const char*>(Awg + (size_t)aoff[tr] * 128);
-        for (int r = w; r < nrec; r += W)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (size_t)r * 1024 + lane * 16),
+        const int nrec = 2 * sload(&tcs[tr]);
+        const char* g0 = reinterpret_cast<const char*>(Awg + (size_t)sload(&aoff[tr]) * 128);
+        const int l16 = lane_now() * 16;
+        for (int r = w_r; r < nrec; r += W)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + (size_t)r * 1024 + l16),
                                            (__attribute__((address_space(3))) void*)(&slds[oRing + (chunk * 2 * T + r) * 128]), 16, 0, 0);
       };
       // stage of the trip's 16 rows: lane a*16 + e of the staging wave(s) holds array a, entry e (e = lane group q * 4 + k-step of
@@ -974,18 +956,22 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
       // 3..3+NB = D * border columns, the rest stays zero), laid out as the B operand of one matrix-core instruction per pair:
       // A~_ct' S gives A~'w1..w3 and the border column of A~'DA~ for column tile ct in one accumulator tile.
       auto stage_load = [&](int tr, double (&reg)[2]) AINL {
-        const int s = 4 * tr, js = s >> 4, e = lane & 15;
+        if (w_r < W - 2) return;
+        const int ln = lane_now();
+        const int s = 4 * tr, js = s >> 4, e = ln & 15;
         const int ix = js * 64 + (e >> 2) * 16 + (s & 15) + (e & 3);
-        const int a = lane >> 4;
+        const int a = ln >> 4;
         reg[0] = reg[1] = 0.0;
-        if (w == W - 1) reg[0] = (a == 0 ? aD : (a == 1 ? aW1 : (a == 2 ? aW2 : aW3)))[ix];
-        if (NB > 0 && w == W - 2 && a < NB) reg[1] = aD[ix] * Abg[(size_t)a * JS + ix];
+        if (w_r == W - 1) reg[0] = (a == 0 ? aD : (a == 1 ? aW1 : (a == 2 ? aW2 : aW3)))[ix];
+        if (NB > 0 && w_r == W - 2 && a < NB) reg[1] = aD[ix] * Abg[(size_t)a * JS + ix];
       };
       auto stage_commit = [&](int buf, const double (&reg)[2]) AINL {
-        const int e = lane & 15, a = lane >> 4, qq = e >> 2, kk = e & 3;
+        if (w_r < W - 2) return;
+        const int ln = lane_now();
+        const int e = ln & 15, a = ln >> 4, qq = e >> 2, kk = e & 3;
         const int si = oC1 + buf * C1S + 16 + (((kk >> 1) * 4 + qq) * 16) * 2 + (kk & 1);   // S[pair kk/2][qq][column][kk & 1]
-        if (w == W - 1) { if (a == 0) slds[oC1 + buf * C1S + e] = reg[0]; else slds[si + (a - 1) * 2] = reg[0]; }
-        if (NB > 0 && w == W - 2 && a < NB) slds[si + (3 + a) * 2] = reg[1];
+        if (w_r == W - 1) { if (a == 0) slds[oC1 + buf * C1S + e] = reg[0]; else slds[si + (a - 1) * 2] = reg[0]; }
+        if (NB > 0 && w_r == W - 2 && a < NB) slds[si + (3 + a) * 2] = reg[1];
       };
       double sreg[2] = {0.0, 0.0};
       v4d sacc[CW];
@@ -1005,9 +991,12 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 #endif
         const int c1 = cht == 2 ? 0 : cht + 1, c2 = c1 == 2 ? 0 : c1 + 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if QP_STAMPS == 3
+        st_acc[15] += __builtin_amdgcn_s_memtime() - tw0_;   // (variant: the wait for my own DMAs alone)
+#endif
         if (t + 1 < ntr) stage_commit(c1, sreg);
         __syncthreads();
-#if QP_STAMPS
+#if QP_STAMPS && QP_STAMPS != 3
         st_acc[15] += __builtin_amdgcn_s_memtime() - tw0_;   // diagnostic build: share of pass 1 spent in the per-trip wait + barrier
 #endif
         if (t + 2 < ntr) { issue(t + 2, c2); stage_load(t + 2, sreg); }
@@ -1020,14 +1009,19 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         constexpr int KK = K > 0 ? K : 1;
         constexpr bool PIPE = K <= 5;     // (more tiles: two pairs of operands in registers next to the accumulators would spill)
         struct POps { v2d dd, sv, bi[KK], bj[KK], bc[CW]; };
+        int bcrec[CW];                    // my column tiles' records in the chunk (record 0 stands in for an inactive one)
+        bool side_on[CW];
+#pragma unroll
+        for (int ci = 0; ci < CW; ++ci) { const int ct = w_r + W * ci; side_on[ci] = ct < tc; bcrec[ci] = side_on[ci] ? ct * 128 : 0; }
         auto ld = [&](int chk, int u, POps& o) AINL {
-          const int rb = oRing + (chk * 2 * T + u * tc) * 128 + lane * 2;
-          o.dd = *reinterpret_cast<const v2d*>(&slds[oC1 + chk * C1S + q * 4 + 2 * u]);
-          o.sv = *reinterpret_cast<const v2d*>(&slds[oC1 + chk * C1S + 16 + u * 128 + lane * 2]);
+          const int ln = lane_now();
+          const int rb = oRing + (chk * 2 * T + u * tc) * 128 + ln * 2;
+          o.dd = *reinterpret_cast<const v2d*>(&slds[oC1 + chk * C1S + (ln >> 4) * 4 + 2 * u]);
+          o.sv = *reinterpret_cast<const v2d*>(&slds[oC1 + chk * C1S + 16 + u * 128 + ln * 2]);
 #pragma unroll
           for (int t = 0; t < K; ++t) { o.bi[t] = *reinterpret_cast<const v2d*>(&slds[rb + tI[t] * 128]); o.bj[t] = *reinterpret_cast<const v2d*>(&slds[rb + tJ[t] * 128]); }
 #pragma unroll
-          for (int ci = 0; ci < CW; ++ci) { const int ct = w + W * ci; o.bc[ci] = *reinterpret_cast<const v2d*>(&slds[rb + (ct < tc ? ct : 0) * 128]); }
+          for (int ci = 0; ci < CW; ++ci) o.bc[ci] = *reinterpret_cast<const v2d*>(&slds[rb + bcrec[ci]]);
         };
         auto mm = [&](const POps& o) AINL {
 #pragma unroll
@@ -1037,7 +1031,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
           // side products of my column tiles: A~_ct' S
 #pragma unroll
           for (int ci = 0; ci < CW; ++ci)
-            if (w + W * ci < tc) {
+            if (side_on[ci]) {
 #pragma unroll
               for (int h = 0; h < 2; ++h) sacc[ci] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.bc[ci][h], o.sv[h], sacc[ci], 0, 0, 0);
             }
@@ -1066,7 +1060,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         }
       };
       for (int tr = 0; tr < ntr;) {
-        const int tc = tcs[tr], tr1 = rend[tr];
+        const int tc = sload(&tcs[tr]), tr1 = sload(&rend[tr]);
         int nact = 0;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) nact += (tJ[t] < tc) ? 1 : 0;
@@ -1085,59 +1079,23 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
         }
         tr = tr1;
       }
+      const int lane_r = lane_now(), q_r = lane_r >> 4, c_r = lane_r & 15;
       // accumulator tile of column tile ct: lane (q, c), register p = entry 16 ct + q + 4 p of side column c
 #pragma unroll
       for (int ci = 0; ci < CW; ++ci) {
-        const int ct = w + W * ci;
+        const int ct = w_r + W * ci;
         if (ct < T) {
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
-            const int i = 16 * ct + q + 4 * p;
-            if (c == 0) P1_(i) = sacc[ci][p];
-            else if (c == 1) P2_(i) = sacc[ci][p];
-            else if (c == 2) P3_(i) = sacc[ci][p];
-            else if (c < 3 + NB) MB_(c - 3, i) = sacc[ci][p];
+            const int i = 16 * ct + q_r + 4 * p;
+            if (c_r == 0) P1_(i) = sacc[ci][p];
+            else if (c_r == 1) P2_(i) = sacc[ci][p];
+            else if (c_r == 2) P3_(i) = sacc[ci][p];
+            else if (c_r < 3 + NB) MB_(c_r - 3, i) = sacc[ci][p];
           }
         }
       }
       __syncthreads();   // the ring region is reused (second set of partial n-vectors) once everybody is through the last chunk
-    } else {
-      // operands straight from global memory, software-pipelined one pair ahead (shapes without LDS room for the ring)
-      auto load_pair = [&](int pi, PairOps& o) AINL {
-        const int tr = pi >> 1, u = pi & 1;
-        const int tc = tcs[tr], rb = aoff[tr] + u * tc;
-        const int s0 = 4 * tr + 2 * u;
-        const int rix = (s0 >> 4) * 64 + q * 16 + (s0 & 15);
-        o.tc = tc;
-        o.dd = *reinterpret_cast<const v2d*>(&aD[rix]); o.w1 = *reinterpret_cast<const v2d*>(&aW1[rix]);
-        o.w2 = *reinterpret_cast<const v2d*>(&aW2[rix]); o.w3 = *reinterpret_cast<const v2d*>(&aW3[rix]);
-#pragma unroll
-        for (int e = 0; e < NB; ++e) o.ab[e] = AB2_(e, rix);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) if (tJ[t] < tc) { o.bi[t] = opnd(rb + tI[t]); o.bj[t] = opnd(rb + tJ[t]); }
-#pragma unroll
-        for (int ci = 0; ci < CW; ++ci) if (w + W * ci < tc) o.bc[ci] = opnd(rb + w + W * ci);
-      };
-      const int npair = 2 * ntr;
-      PairOps cur, nxt;
-      if (npair > 0) load_pair(0, cur);
-      for (int pi = 0; pi < npair; ++pi) {
-        if (pi + 1 < npair) load_pair(pi + 1, nxt);
-        do_pair(cur);
-        cur = nxt;
-      }
-      if (NB > 0) __syncthreads();   // the border sums of every wave are in the scratch
-    }
-    if constexpr (!RING)
-#pragma unroll
-    for (int ci = 0; ci < CW; ++ci) {
-      const int ct = w + W * ci;
-      if (ct < T) {
-        const double v1 = q_sum(p1[ci]), v2 = q_sum(p2[ci]), v3 = q_sum(p3[ci]);
-        if (q == 0) { P1_(16 * ct + c) = v1; P2_(16 * ct + c) = v2; P3_(16 * ct + c) = v3; }
-#pragma unroll
-        for (int e = 0; e < NB; ++e) { const double vb = q_sum(pb[e][ci]); if (q == 0) MB_(e, 16 * ct + c) = vb; }
-      }
     }
     if constexpr (NB > 0) {
       constexpr int NSUM = NB * (NB + 1) / 2 + 3 * NB;
@@ -1189,6 +1147,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
       const double sc = fmax(1.0, fmax(fabs(G_(i)), fmax(fabs(HX_(i)), fabs(gz))));
       m_rd = fmax(m_rd, fabs(HX_(i) + G_(i) - gz) / sc);
     }
+    XCAP(0);
     const double fval = wave_sum(fl);
     const double rd_rel = wave_max(m_rd);
     const double gap_rel = gap / fmax(1.0, fabs(fval));
@@ -1247,6 +1206,7 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
       if (have_saved) { flag = 2; break; }
     } else if (have_saved && merit > P.tol_loose) { flag = 2; break; }
     if (merit < 0.9 * best_res) { best_res = merit; stall = 0; } else ++stall;
+    XCAP(1);
 
     // ================= factorise with the affine / centering right-hand sides riding along =================
     for (int i = tid; i < np; i += NTH) {
@@ -1279,7 +1239,10 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
     }
     __syncthreads();
 #endif
+    XCAP(2);
+#if QP_STAMPS != 2
     STAMP(4);
+#endif
     if (factor_solve2(true)) {
       flag = (res_ok || have_saved) ? 2 : -1;
       // the factorisation broke down (weights ~1e24) on an iterate that is nearly primal feasible and complementary: its working
@@ -1853,20 +1816,15 @@ template <int T, int NB, int W, bool RING> __global__ __launch_bounds__(64 * W, 
 
 }  // namespace
 
-template <int T, int NB, int W, bool RING> static hipError_t launch_wg(const QpParams& P, int batch, hipStream_t st) {
-  const size_t lds = qp_wg_lds_base_bytes(P.d, W, NB, RING);
+template <int T, int NB, int W> static hipError_t launch_wg(const QpParams& P, int batch, hipStream_t st) {
+  const size_t lds = qp_wg_lds_base_bytes(P.d, W, NB);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_wg_kernel<T, NB, W, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_wg_kernel<T, NB, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((qp_wg_kernel<T, NB, W, RING>), dim3(batch), dim3(64 * W), lds, st, P);
+  hipLaunchKernelGGL((qp_wg_kernel<T, NB, W>), dim3(batch), dim3(64 * W), lds, st, P);
   return hipGetLastError();
 }
-// the ring variant wherever the LDS budget has room for it (qp_make_dims decides: d.wg_ring); the largest shapes stream from global memory
-template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P, int batch, hipStream_t st) {
-  if (P.d.wg_ring) return launch_wg<T, NB, QP_WG_W, true>(P, batch, st);
-  if constexpr (T >= QP_WG_NORING_MIN_T) return launch_wg<T, NB, QP_WG_W, false>(P, batch, st);
-  return hipErrorInvalidValue;
-}
+template <int T, int NB> static hipError_t launch_wg_T(const QpParams& P, int batch, hipStream_t st) { return launch_wg<T, NB, QP_WG_W>(P, batch, st); }
 
 #ifndef QP_WG_TLO
 #define QP_WG_TLO 1
