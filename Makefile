@@ -17,17 +17,19 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/qp_solver.h $(CSRC)/ltv_build.h $(CSRC)/ref
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(HIPFLAGS)
 
+# WGFLAGS (both solve kernels): without machine LICM and with sinking-to-avoid-spills the T = 8 workgroup kernel spills 20 VGPRs
+# instead of 166 (256 are its budget at two waves per SIMD) and the one-wavefront kernels need no scratch at all (T = 5: 140..504
+# bytes per lane before): hoisted address arithmetic no longer lives across the whole iteration loop.
+WGFLAGS := -mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1
+
 # qp_solver.hip is compiled as six translation units (see the note in the file): main + the tile counts T = 1..4, 5, 6, 7
 QPOBJ := $(LIBDIR)/qp_solver_tu0.o $(LIBDIR)/qp_solver_tu1.o $(LIBDIR)/qp_solver_tu2.o $(LIBDIR)/qp_solver_tu3.o $(LIBDIR)/qp_solver_tu4.o
 $(LIBDIR)/qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
-	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_TU=$*
+	$(CC_CHECKED) $@ $< $(HIPFLAGS) $(WGFLAGS) -DQP_TU=$*
 
-# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 1..12) is compiled once per range of tile counts (lo_hi).
-# WGFLAGS: without machine LICM and with sinking-to-avoid-spills the T = 8 kernel spills 8 VGPRs instead of 166 (256 are its budget
-# at two waves per SIMD): hoisted address arithmetic no longer lives across the whole iteration loop.
-WGFLAGS := -mllvm -disable-machine-licm -mllvm -sink-insts-to-avoid-spills=1
-WGOBJ := $(LIBDIR)/qp_wg_1_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_7_8.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o
+# qp_wg.hip (workgroup-per-QP solve kernel, tile counts T = 1..12) is compiled once per range of tile counts (lo_hi)
+WGOBJ := $(LIBDIR)/qp_wg_1_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_7_7.o $(LIBDIR)/qp_wg_8_8.o $(LIBDIR)/qp_wg_9_9.o $(LIBDIR)/qp_wg_10_10.o $(LIBDIR)/qp_wg_11_11.o $(LIBDIR)/qp_wg_12_12.o
 $(LIBDIR)/qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(HIPFLAGS) $(WGFLAGS) -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
@@ -43,14 +45,14 @@ $(LIBDIR)/libfsaempc.so: $(QPOBJ) $(WGOBJ) $(COMMON)
 
 # development builds of the workgroup kernel: ONE instantiation (T = 8 + slack border: BASELINE configs[2], dynamic N = 60) linked with the
 # shipped objects of everything else; plain and with phase stamps.  Select with FSAEMPC_LIB.
-WGDEVFLAGS := $(WGFLAGS) -DQP_WG_TLO=8 -DQP_WG_THI=8 -DQP_WG_SYM=7 -DQP_WG_ONLY_NB=4
+WGDEVFLAGS := $(WGFLAGS) -DQP_WG_TLO=8 -DQP_WG_THI=8 -DQP_WG_ONLY_NB=4
 $(LIBDIR)/wgdev_qp_wg.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(WGDEVFLAGS) -c $< -o $@
 $(LIBDIR)/wgdevst_qp_wg.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) $(WGDEVFLAGS) -DQP_STAMPS=1 -c $< -o $@
-WGDEVREST := $(QPOBJ) $(LIBDIR)/qp_wg_1_5.o $(LIBDIR)/qp_wg_6_6.o $(LIBDIR)/qp_wg_9_10.o $(LIBDIR)/qp_wg_11_12.o $(COMMON)
+WGDEVREST := $(QPOBJ) $(filter-out $(LIBDIR)/qp_wg_8_8.o,$(WGOBJ)) $(COMMON)
 wgdev: $(LIBDIR)/libfsaempc_wgdev.so $(LIBDIR)/libfsaempc_wgdevst.so
 $(LIBDIR)/libfsaempc_wgdev.so: $(LIBDIR)/wgdev_qp_wg.o $(WGDEVREST)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
@@ -64,16 +66,17 @@ $(LIBDIR)/dbg_qp_wg_%.o: $(CSRC)/qp_wg.hip $(CSRC)/qp_solver.h include/fsaempc.h
 	$(CC_CHECKED) $@ $< $(HIPFLAGS) $(WGFLAGS) -DQP_DEBUG_DUMP -DQP_WG_TLO=$(word 1,$(subst _, ,$*)) -DQP_WG_THI=$(word 2,$(subst _, ,$*))
 $(LIBDIR)/dbg_qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
-	$(CC_CHECKED) $@ $< $(HIPFLAGS) -DQP_DEBUG_DUMP -DQP_TU=$*
+	$(CC_CHECKED) $@ $< $(HIPFLAGS) $(WGFLAGS) -DQP_DEBUG_DUMP -DQP_TU=$*
 dbg: $(LIBDIR)/libfsaempc_dbg.so
 $(LIBDIR)/libfsaempc_dbg.so: $(DBGOBJ) $(LIBDIR)/qp_solver_tu3.o $(LIBDIR)/qp_solver_tu4.o $(filter-out $(LIBDIR)/qp_wg_1_5.o,$(WGOBJ)) $(COMMON)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 # guard build: the solver sources at -O1, every instantiated (T, NB) (tests/test_gpu_parity.py::test_shipped_build_matches_O1_build
 # compares the two builds on the GPU; see DESIGN.md "Build-variant fragility")
-O1FLAGS := --offload-arch=$(ARCH) -O1 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wno-unused-function
+O1FLAGS := --offload-arch=$(ARCH) -O1 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wno-unused-function $(WGFLAGS)
 O1OBJ := $(LIBDIR)/o1_qp_solver_tu0.o $(LIBDIR)/o1_qp_solver_tu1.o $(LIBDIR)/o1_qp_solver_tu2.o $(LIBDIR)/o1_qp_solver_tu3.o $(LIBDIR)/o1_qp_solver_tu4.o \
-         $(LIBDIR)/o1_qp_wg_1_5.o $(LIBDIR)/o1_qp_wg_6_6.o $(LIBDIR)/o1_qp_wg_7_8.o $(LIBDIR)/o1_qp_wg_9_10.o $(LIBDIR)/o1_qp_wg_11_12.o
+         $(LIBDIR)/o1_qp_wg_1_5.o $(LIBDIR)/o1_qp_wg_6_6.o $(LIBDIR)/o1_qp_wg_7_7.o $(LIBDIR)/o1_qp_wg_8_8.o $(LIBDIR)/o1_qp_wg_9_9.o $(LIBDIR)/o1_qp_wg_10_10.o \
+         $(LIBDIR)/o1_qp_wg_11_11.o $(LIBDIR)/o1_qp_wg_12_12.o
 $(LIBDIR)/o1_qp_solver_tu%.o: $(CSRC)/qp_solver.hip $(CSRC)/qp_solver.h include/fsaempc.h $(CHECKDEPS)
 	@mkdir -p $(LIBDIR)
 	$(CC_CHECKED) $@ $< $(O1FLAGS) -DQP_TU=$*

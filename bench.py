@@ -182,9 +182,17 @@ def main():
     achieved = flops_launch / (k_ms * 1e-3) / 1e12
     bytes_solve = 8.0 * (nV * nV + nV + nC * nV + 2 * nV + 2 * nC) + 8.0 * (nV + 2)
 
+    # tile count / border width as qp_make_dims chooses them: nV mod 16 in 1..4 is a border; else LTV-shaped QPs keep their trailing
+    # slack columns as the border behind a core padded to a multiple of 16
     rem = nV % 16
-    Tt, NBt = (nV // 16, 1 if rem == 1 else 4) if (nV >= 16 and 1 <= rem <= 4) else ((nV + 15) // 16, 0)
-    kernel_name = ("qp_solve_kernel<%d, %d>" % (Tt, NBt)) if Tt <= 7 else "qp_wg_kernel<%d, %d, 8, ...>" % (Tt, 4 if NBt else 0)   # qp_launch's choice
+    ns_ = 4 if nC == 10 * (nV - 4) else (1 if nC == 3 * (nV - 1) else 0)
+    if nV >= 16 and 1 <= rem <= 4:
+        Tt, NBt = nV // 16, (1 if rem == 1 else 4)
+    elif ns_ and nV >= 20:
+        Tt, NBt = (nV - ns_ + 15) // 16, (1 if ns_ == 1 else 4)
+    else:
+        Tt, NBt = (nV + 15) // 16, 0
+    kernel_name = ("qp_solve_kernel<%d, %d>" % (Tt, NBt)) if Tt <= 7 else "qp_wg_kernel<%d, %d, 8>" % (Tt, 4 if NBt else 0)   # qp_launch's choice
     res = {
         "metric": "QP solves/sec (batched LTV-MPC, N=%d nx=%d nu=2 fp64)" % (N, nx),
         "value": value, "unit": "QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -211,13 +219,14 @@ def main():
 
     # Counter-based figures of the dominant kernel are ARCHIVED measurements (rocprofv3 --pmc needs its own passes and cannot run
     # inside this process): HBM-side traffic (tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections) and
-    # matrix-core busy share (SQ_VALU_MFMA_BUSY_CYCLES pass), committed under profiles/round2/ for exactly this workload
-    for key, fname, field in (("traffic", "pmc_traffic_kinN40_B4096.json", "traffic_bytes_per_launch"), ("mfma_busy", "pmc_mfma_kinN40_B4096.json", "mfma_busy_frac")):
-        path = os.path.join(ROOT, "profiles", "round2", fname)
-        if os.path.exists(path) and args.model == "kinematic" and N == 40 and Bl == 4096:
+    # matrix-core busy share (SQ_VALU_MFMA_BUSY_CYCLES pass), committed under profiles/round3/ for exactly this workload (headline and configs[2] shape)
+    tag = "%sN%d_B%d" % ("kin" if args.model == "kinematic" else "dyn", N, Bl)
+    for key, fname, field in (("traffic", "pmc_traffic_%s.json" % tag, "traffic_bytes_per_launch"), ("mfma_busy", "pmc_mfma_%s.json" % tag, "mfma_busy_frac")):
+        path = os.path.join(ROOT, "profiles", "round3", fname)
+        if os.path.exists(path):
             with open(path) as f:
                 res["roofline"][key] = json.load(f)[field]
-            res["roofline"][key + "_source"] = "archived PMC pass of this workload: profiles/round2/" + fname
+            res["roofline"][key + "_source"] = "archived PMC pass of this workload: profiles/round3/" + fname
     if res["roofline"]["traffic"] is not None:
         res["roofline"]["traffic_unit"] = "bytes per launch (L2-miss side; Infinity-Cache hits are counted, so an upper bound on HBM bytes)"
 

@@ -71,7 +71,7 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double*
   if ((wg ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
-  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr;
+  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr; P.x_init = aux ? aux->x_init : nullptr;
   P.shared_HA = desc->shared_HA;
   { const int st = g_dump_stage.load(); P.dump = g_dump.load(); P.dump_stage = st & 0xff; P.dump_iter = st >> 8; }
   const bool timing = g_timing.load();

@@ -47,6 +47,8 @@ struct QpParams {
   int* polished;   // optional per-instance output: >0 if the active-set refinement was accepted (attempt count), <0 reason of rejection
   double* kkt;     // optional per-instance output: relative KKT residual of the returned point as the kernel measured it
   double* dump; int dump_stage, dump_iter;
+  const double* x_init;   // optional starting point, batch x nu in the caller's variables (null: x = clamp(0, lb, ub)); clamped to the bounds.
+                          // Slacks and multipliers start as always (profiles/round3/warm_start_ab.json: what that is worth)
 };
 
 void qp_make_dims(int n, int m, QpDims* d);

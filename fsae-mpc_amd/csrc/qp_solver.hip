@@ -119,9 +119,12 @@ template <int T> struct Tri {
 // ---------------------------------------------------------------------------------------------
 // qp_prep_kernel: scaling (E columns, F rows), repack of A and H, scaled g / bounds.  One wave per QP.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
-  // one 256-thread workgroup per QP (4 wavefronts share the LDS staging tile; HBM-bound: ~0.5 MB moved per QP)
+__global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
+  // one workgroup per QP: 256 threads for small row counts, 1024 for large ones (qp_launch_prep) -- the staging tile allows one
+  // workgroup per CU there, and with four wavefronts the dependent LDS -> global chains of the repack ran at a tenth of the
+  // memory rate (11 ms of a 145 ms dynamic N = 60 batch)
   const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, q = lane >> 4;
+  const int NTH = blockDim.x, NW = NTH >> 6;
   const QpDims& d = P.d;
   const int n = d.n, nu = d.nu, m = d.m, T = d.T, Kq = d.Kq, J = d.J, JB = d.JB, np = d.np, nc = d.nc, nb = d.nb;
   const double* H = P.H + (P.shared_HA ? 0 : (size_t)b * nu * nu);
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   double* Ur = ws + d.off_rows + 1 * (size_t)d.rowlen;
   extern __shared__ double lds[];
   double* Esh = lds;            // np
-  double* red = lds + np;       // 4 partial maxima
-  double* tile = red + 4;       // 16 x (4Kq+1) staging for the A transpose
+  double* red = lds + np;       // 16 partial maxima
+  double* tile = red + 16;       // 16 x (4Kq+1) staging for the A transpose
   const int TW = d.prep_tw;     // columns staged per pass (16, or fewer when 16 x 4Kq doubles would not fit the LDS)
   int* cls_sh = reinterpret_cast<int*>(tile + TW * (4 * Kq + 1));   // [4Kq] tile class of every original row
   int* perm_sh = cls_sh + 4 * Kq;                                    // [16 ntr] original row of every sorted position
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   double* Fr_sh = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(chc_sh + ((m + 63) >> 6) * 16) + 7) & ~(uintptr_t)7);   // [m] row scale of every original row
 
   // ---- column scaling E_j = 1/sqrt(H_jj), or 1/max|A_:j| where H_jj ~ 0 (slack columns) ----
-  for (int j = tid; j < np; j += 256) {
+  for (int j = tid; j < np; j += NTH) {
     double e = 1.0;
     if (j < n) {
       double hjj = Hat(j, j);
@@ -174,17 +177,17 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   for (int j = 0; j < n; ++j) {
     if (Esh[j] < 0) {  // uniform over the workgroup
       double cm = 0;
-      for (int r = tid; r < m; r += 256) cm = fmax(cm, fabs(Aat(r, j)));
+      for (int r = tid; r < m; r += NTH) cm = fmax(cm, fabs(Aat(r, j)));
       cm = wave_max(cm);
       if (lane == 0) red[w] = cm;
       __syncthreads();
-      if (tid == 0) { const double mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])); Esh[j] = mx > 1e-12 ? 1.0 / mx : 1.0; }
+      if (tid == 0) { double mx = 0.0; for (int i = 0; i < NW; ++i) mx = fmax(mx, red[i]); Esh[j] = mx > 1e-12 ? 1.0 / mx : 1.0; }
       __syncthreads();
     }
   }
   int bad = 0;   // NaN / Inf anywhere in H, g, A or NaN in a bound: the solve kernel answers -1 before its first iteration (the
                  // reference's MEX gateway rejects such a call; a device entry cannot look at the data before the launch)
-  for (int j = tid; j < np; j += 256) { const int uj = j < n ? U(j) : -1; const double gj = uj >= 0 ? g[uj] : 0.0; Es[j] = Esh[j]; gw[j] = gj * Esh[j]; bad |= !(fabs(gj) < INFINITY); }
+  for (int j = tid; j < np; j += NTH) { const int uj = j < n ? U(j) : -1; const double gj = uj >= 0 ? g[uj] : 0.0; Es[j] = Esh[j]; gw[j] = gj * Esh[j]; bad |= !(fabs(gj) < INFINITY); }
 
   // ---- one pass over A, thread = row (coalesced: consecutive threads read consecutive rows of a column, the loads of a thread are
   //      independent): row scaling F_r = 1 / max_j |A[r][j] E_j| and the row's class = last core column tile with a nonzero.
@@ -193,10 +196,10 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   __syncthreads();   // Esh complete
   const int ncols = nc < n ? nc : n;
   const int nchunk = (m + 63) >> 6;
-  for (int i = tid; i < nchunk * 16; i += 256) chc_sh[i] = 0;
+  for (int i = tid; i < nchunk * 16; i += NTH) chc_sh[i] = 0;
   if (tid < 16) cnt_sh[tid] = 0;
   __syncthreads();
-  for (int r0 = 0; r0 < m; r0 += 256) {
+  for (int r0 = 0; r0 < m; r0 += NTH) {
     const int r = r0 + tid;
     int e = 0;
     double rm = 0.0;
@@ -227,9 +230,9 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     for (int cl = 0; cl < tid; ++cl) start += cnt_sh[cl];
     for (int ch = 0; ch < nchunk; ++ch) { const int cn = chc_sh[ch * 16 + tid]; chc_sh[ch * 16 + tid] = start; start += cn; }
   }
-  for (int p = tid; p < 16 * ntr; p += 256) perm_sh[p] = -1;
+  for (int p = tid; p < 16 * ntr; p += NTH) perm_sh[p] = -1;
   __syncthreads();
-  for (int r0 = 0; r0 < m; r0 += 256) {   // part 2: position = start of (chunk, class) + rank among the chunk's earlier rows of the class
+  for (int r0 = 0; r0 < m; r0 += NTH) {   // part 2: position = start of (chunk, class) + rank among the chunk's earlier rows of the class
     const int r = r0 + tid;
     const int e = r < m ? cls_sh[r] : -1;
     for (int cl = 0; cl < T; ++cl) {
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   }
   __syncthreads();
   // tiles per trip (16 sorted positions), stream offsets, phase ends
-  for (int tr = tid; tr < ntr; tr += 256) {
+  for (int tr = tid; tr < ntr; tr += NTH) {
     int tc = 1;
     for (int p = 16 * tr; p < 16 * tr + 16; ++p) { const int r = perm_sh[p]; if (r >= 0) tc = max(tc, cls_sh[r] + 1); }
     tcs_sh[tr] = tc;
@@ -252,10 +255,10 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     for (int C = 0; C <= T; ++C) { int cn = 0; for (int tr = 0; tr < ntr; ++tr) cn += (tcs_sh[tr] <= C); tend_g[C] = cn; }
   }
   __syncthreads();
-  for (int tr = tid; tr <= ntr; tr += 256) { aoff_g[tr] = aoff_sh[tr]; if (tr < ntr) tcs_g[tr] = tcs_sh[tr]; }
+  for (int tr = tid; tr <= ntr; tr += NTH) { aoff_g[tr] = aoff_sh[tr]; if (tr < ntr) tcs_g[tr] = tcs_sh[tr]; }
 
   // ---- row scaling F_r = 1/max_j |A[r][j] E_j| ; rows handled in owner layout, one slot per wavefront and trip ----
-  for (int js = w; js < J; js += 4) {
+  for (int js = w; js < J; js += NW) {
     const int s = 16 * js + c, pp = 4 * s + q;
     const int r = (s < 4 * ntr) ? perm_sh[pp] : -1;
     const bool valid = r >= 0;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     Lr[js * 64 + lane] = l;
     Ur[js * 64 + lane] = u;
   }
-  for (int jb = w; jb < JB; jb += 4) {
+  for (int jb = w; jb < JB; jb += NW) {
     const int i = jb * 64 + lane;
     double l = -INFINITY, u = INFINITY;
     const int ui = i < n ? U(i) : -1;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
   const int R4 = 4 * Kq, mp1 = R4 + 1;  // padded LDS row length (odd => conflict-free across the 16 columns)
   for (int t = 0; t < T; ++t)
     for (int c0 = 0; c0 < 16; c0 += TW) {
-      for (int e = tid; e < TW * R4; e += 256) {
+      for (int e = tid; e < TW * R4; e += NTH) {
         const int cc = e / R4, r = e - cc * R4;
         const int col = 16 * t + c0 + cc;
         double v = 0.0;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
         tile[cc * mp1 + r] = v;
       }
       __syncthreads();
-      for (int s = w; s < 4 * ntr; s += 4) {   // k-steps are stored in pairs (16 B per lane and load); padded positions carry zeros
+      for (int s = w; s < 4 * ntr; s += NW) {   // k-steps are stored in pairs (16 B per lane and load); padded positions carry zeros
         const int tr = s >> 2, tc = tcs_sh[tr];
         if (t < tc && c >= c0 && c < c0 + TW) {
           const int r = perm_sh[4 * s + q];
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     }
 
   // ---- H -> accumulator-layout tiles (T x T grid of the core; symmetric read for coalescing) ----
-  for (int idx = w; idx < T * T * 4; idx += 4) {
+  for (int idx = w; idx < T * T * 4; idx += NW) {
     const int p = idx & 3, IJ = idx >> 2, I = IJ / T, Jt = IJ - I * T;
     const int row = 16 * I + q + 4 * p, col = 16 * Jt + c;
     double v = 0.0;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256) void qp_prep_kernel(QpParams P) {
     bad |= !(fabs(v) < INFINITY);
     Hw[(size_t)idx * 64 + lane] = v;
   }
-  for (int e = tid; e < 4 * np; e += 256) {
+  for (int e = tid; e < 4 * np; e += NTH) {
     const int bb = e / np, i = e - bb * np;
     const double v = (bb < nb && i < n) ? Hat(i, nc + bb) * Esh[nc + bb] * Esh[i] : 0.0;
     bad |= !(fabs(v) < INFINITY);
@@ -1195,6 +1198,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       const int i = (js - J) * 64 + lane;
       if (i < k.np) {
         double xi = 0.0;
+        if (P.x_init) { const int ui = i < k.n ? qp_user_index(d, i) : -1; if (ui >= 0) { const double xs = P.x_init[(size_t)b * d.nu + ui] / EV[i]; if (fabs(xs) < INFINITY) xi = xs; } }
         if (valid) { if (l > -INFINITY && xi < l) xi = l; if (u < INFINITY && xi > u) xi = u; }
         X[i] = xi;
       }
@@ -1983,7 +1987,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
           if (l > -INFINITY && zi < l) viol = l - zi;
           if (u < INFINITY && zi > u) viol = fmax(viol, zi - u);
           m_rp = fmax(m_rp, viol / fmax(1.0, fabs(zi)));
-          fl2 += 0.5 * zi * HX[i] + G[i] * zi;
+          fl2 += 0.5 * zi * HX[i] + G[i] * zi + 0.0 * r;   // (0 * r: a non-finite residual must poison the sum -- fmax drops NaN operands)
         }
       }
       for (int js = 0; js < J; ++js) {
@@ -1999,6 +2003,7 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
           if (u < INFINITY && v > u) viol = fmax(viol, v - u);
           m_rp = fmax(m_rp, viol / sc);
           m_sg = fmax(m_sg, (sd > 0 ? -y : (sd < 0 ? y : 0.0)) / fmax(1.0, fabs(y)));
+          fl2 += 0.0 * (v + y);
         }
       }
       m_rd = wave_max(m_rd); m_rp = wave_max(m_rp); m_sg = wave_max(m_sg); m_cp = wave_max(m_cp);
@@ -2011,8 +2016,8 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
       // the active soft rows: the floor of any fp64 evaluation of this residual; qpOASES' own terminationTolerance is
       // 5e6 eps = 1.1e-9, qpOASES_options.m:190), feasibility and complementarity 1e-10, multipliers of the right sign
       // (round-off level wrong signs are zeroed)
-      pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8;
-      if (!pok) flag_polished = !(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3));
+      pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8 && fabs(f2) < INFINITY;   // (f2 is NaN if anything in the candidate is not finite)
+      if (!pok) flag_polished = !(fabs(f2) < INFINITY) ? -5 : (!(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3)));
       if (!pok && m_rd <= 1e-8 && attempt < QP_REFINE_ATTEMPTS - 1 && (m_rp > 1e-10 || m_sg > 1e-8)) {
         // single correction of the working set: add the most violated inactive row, else drop the worst wrong-sign row
         double my = 0.0; int myix = -1; double myside = 0.0;
@@ -2312,7 +2317,7 @@ void qp_make_dims(int n, int m, QpDims* d) {
   }
   d->prep_tw = 16;
   for (;;) {
-    d->lds_prep = ((size_t)d->np + 4 + (size_t)d->prep_tw * (4 * d->Kq + 1) + (size_t)m + 2) * sizeof(double) +
+    d->lds_prep = ((size_t)d->np + 16 + (size_t)d->prep_tw * (4 * d->Kq + 1) + (size_t)m + 2) * sizeof(double) +
                   ((size_t)4 * d->Kq + 16 * (size_t)d->ntr + 16 + 2 * (size_t)d->ntr + 1 + (size_t)((m + 63) / 64) * 16 + 6) * sizeof(int);
     if (d->lds_prep <= 96 * 1024 || d->prep_tw == 2) break;   // keep the staging tile small enough for more than one workgroup per CU
     d->prep_tw >>= 1;
@@ -2387,18 +2392,27 @@ bool qp_runs_wavefront_kernel(const QpDims& d) {   // what qp_launch will pick (
 hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
 static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) { return qp_wg_launch_1(P, batch, st); }
 #else
+// one translation unit of qp_wg.hip per tile count from T = 6 on (T = 1..5 share one: no bordered variants there): the build is
+// bound by the largest kernels, and they compile side by side this way
 hipError_t qp_wg_launch_1(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_6(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_7(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_8(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_9(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_10(const QpParams& P, int batch, hipStream_t st);
 hipError_t qp_wg_launch_11(const QpParams& P, int batch, hipStream_t st);
+hipError_t qp_wg_launch_12(const QpParams& P, int batch, hipStream_t st);
 static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) {
-  const int T = P.d.T;
-  if (T <= 5) return qp_wg_launch_1(P, batch, st);
-  if (T == 6) return qp_wg_launch_6(P, batch, st);
-  if (T == 7 || T == 8) return qp_wg_launch_7(P, batch, st);
-  if (T == 9 || T == 10) return qp_wg_launch_9(P, batch, st);
-  if (T == 11 || T == 12) return qp_wg_launch_11(P, batch, st);
+  switch (P.d.T) {
+    case 1: case 2: case 3: case 4: case 5: return qp_wg_launch_1(P, batch, st);
+    case 6: return qp_wg_launch_6(P, batch, st);
+    case 7: return qp_wg_launch_7(P, batch, st);
+    case 8: return qp_wg_launch_8(P, batch, st);
+    case 9: return qp_wg_launch_9(P, batch, st);
+    case 10: return qp_wg_launch_10(P, batch, st);
+    case 11: return qp_wg_launch_11(P, batch, st);
+    case 12: return qp_wg_launch_12(P, batch, st);
+  }
   return hipErrorInvalidValue;
 }
 #endif
@@ -2406,7 +2420,7 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_prep);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(256), P.d.lds_prep, st, P);
+  hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(P.d.m > 256 ? 1024 : 256), P.d.lds_prep, st, P);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_mid) { e = hipEventRecord(ev_mid, st); if (e != hipSuccess) return e; }

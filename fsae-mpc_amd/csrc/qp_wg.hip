@@ -159,19 +159,13 @@ DEVINL int diag_factor(int c, int q, v4d& Ud, v4d& Yk, double floor_abs) {
 #ifndef QP_STAMPS
 #define QP_STAMPS 0
 #endif
-#if QP_STAMPS   // diagnostic build only: cycles of wave 0 per phase (barrier waits included), written to P.dump[b*16 + phase]
-#define STAMP_DECL unsigned long long st_xs[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_acc[16]; for (int i_ = 0; i_ < 16; ++i_) st_acc[i_] = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#if QP_STAMPS   // diagnostic build only: cycles of wave 0 per phase (barrier waits included), written to P.dump[b*16 + phase].  The factorisation
+                // and the solves are shared with the refinement: its calls land in their phases (read 5..7 as main loop + refinement)
+#define STAMP_DECL unsigned long long st_acc[16]; for (int i_ = 0; i_ < 16; ++i_) st_acc[i_] = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #define STAMP(id) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[id] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#if QP_STAMPS == 2   // slots 8..15 instead: per wave, cycles from the end of pass 1 to the arrival at the factorisation's first barrier
-#define STAMP_OUT do { if (P.dump && P.dump_stage == 9 && tid == 0) { for (int i_ = 0; i_ < 8; ++i_) { P.dump[(size_t)b * 16 + i_] = (double)st_acc[i_]; P.dump[(size_t)b * 16 + 8 + i_] = (double)st_xs[i_]; } } } while (0)
-#define XCAP(k) do { __builtin_amdgcn_sched_barrier(0); st_xs[k] += __builtin_amdgcn_s_memtime() - st_t0; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
 #define STAMP_OUT do { if (P.dump && P.dump_stage == 9 && tid == 0) for (int i_ = 0; i_ < 16; ++i_) P.dump[(size_t)b * 16 + i_] = (double)st_acc[i_]; } while (0)
-#define XCAP(k) do { } while (0)
-#endif
 #else
 #define STAMP_DECL
-#define XCAP(k) do { } while (0)
 #define STAMP(id) do { } while (0)
 #define STAMP_OUT do { } while (0)
 #endif
@@ -328,6 +322,7 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
       if (i < np) {
         const double l = aL[ix], u = aU[ix];
         double xi = 0.0;
+        if (P.x_init) { const int ui = i < n ? qp_user_index(d, i) : -1; if (ui >= 0) { const double xs = P.x_init[(size_t)b * d.nu + ui] / EV_(i); if (fabs(xs) < INFINITY) xi = xs; } }
         if (l > -INFINITY && xi < l) xi = l;
         if (u < INFINITY && xi > u) xi = u;
         X_(i) = xi;
@@ -770,7 +765,6 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
         for (int p = 0; p < 4; ++p)
           if (mine && p == (c >> 2)) { acc[t][p] += dadd; dmax_l = fmax(dmax_l, acc[t][p]); }
       }
-    XCAP(3);
     if (NB > 0) {
       for (int i = tid; i < np; i += NTH) {
 #pragma unroll
@@ -781,7 +775,6 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
         }
       }
     }
-    XCAP(5);
     red_put(0, wave_max(dmax_l));
     __syncthreads();
     const double dmax = red_max(0);
@@ -789,7 +782,7 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
     const double floor_abs = 1e-30 * dmax;
     STAMP(5);
     int fbad = 0;
-#pragma unroll
+#pragma unroll 1   // (run-time loop over the block steps: same speed as unrolled, an eighth of the code)
     for (int K = 0; K < T; ++K) {
       // A: the diagonal tile (its owner arrives here straight from its trailing update of step K-1)
 #pragma unroll
@@ -991,12 +984,9 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
 #endif
         const int c1 = cht == 2 ? 0 : cht + 1, c2 = c1 == 2 ? 0 : c1 + 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if QP_STAMPS == 3
-        st_acc[15] += __builtin_amdgcn_s_memtime() - tw0_;   // (variant: the wait for my own DMAs alone)
-#endif
         if (t + 1 < ntr) stage_commit(c1, sreg);
         __syncthreads();
-#if QP_STAMPS && QP_STAMPS != 3
+#if QP_STAMPS
         st_acc[15] += __builtin_amdgcn_s_memtime() - tw0_;   // diagnostic build: share of pass 1 spent in the per-trip wait + barrier
 #endif
         if (t + 2 < ntr) { issue(t + 2, c2); stage_load(t + 2, sreg); }
@@ -1147,7 +1137,6 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
       const double sc = fmax(1.0, fmax(fabs(G_(i)), fmax(fabs(HX_(i)), fabs(gz))));
       m_rd = fmax(m_rd, fabs(HX_(i) + G_(i) - gz) / sc);
     }
-    XCAP(0);
     const double fval = wave_sum(fl);
     const double rd_rel = wave_max(m_rd);
     const double gap_rel = gap / fmax(1.0, fabs(fval));
@@ -1206,7 +1195,6 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
       if (have_saved) { flag = 2; break; }
     } else if (have_saved && merit > P.tol_loose) { flag = 2; break; }
     if (merit < 0.9 * best_res) { best_res = merit; stall = 0; } else ++stall;
-    XCAP(1);
 
     // ================= factorise with the affine / centering right-hand sides riding along =================
     for (int i = tid; i < np; i += NTH) {
@@ -1239,10 +1227,7 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
     }
     __syncthreads();
 #endif
-    XCAP(2);
-#if QP_STAMPS != 2
     STAMP(4);
-#endif
     if (factor_solve2(true)) {
       flag = (res_ok || have_saved) ? 2 : -1;
       // the factorisation broke down (weights ~1e24) on an iterate that is nearly primal feasible and complementary: its working
@@ -1693,7 +1678,7 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
           if (l > -INFINITY && zi < l) viol = l - zi;
           if (u < INFINITY && zi > u) viol = fmax(viol, zi - u);
           m_rp = fmax(m_rp, viol / fmax(1.0, fabs(zi)));
-          fl2 += 0.5 * zi * HX_(i) + G_(i) * zi;
+          fl2 += 0.5 * zi * HX_(i) + G_(i) * zi + 0.0 * r;   // (0 * r: a non-finite residual must poison the sum -- fmax drops NaN operands)
         }
         for (int js = w; js < J; js += W) {
           const int ix = js * 64 + lane;
@@ -1708,6 +1693,7 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
             if (u < INFINITY && v > u) viol = fmax(viol, v - u);
             m_rp = fmax(m_rp, viol / sc);
             m_sg = fmax(m_sg, (sd > 0 ? -y : (sd < 0 ? y : 0.0)) / fmax(1.0, fabs(y)));
+            fl2 += 0.0 * (v + y);
           }
         }
         red_put(0, wave_max(m_rd)); red_put(1, wave_max(m_rp)); red_put(2, wave_max(m_sg)); red_put(3, wave_max(m_cp)); red_put(4, wave_sum(fl2));
@@ -1717,8 +1703,8 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
         red_next();
         // acceptance: relative stationarity 1e-8, feasibility and complementarity 1e-10, multipliers of the right sign (the same
         // thresholds as the one-wavefront kernel)
-        pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8;
-        if (!pok) flag_polished = !(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3));
+        pok = m_rd <= 1e-8 && m_rp <= 1e-10 && m_cp <= 1e-10 * fmax(1.0, fabs(f2)) && m_sg <= 1e-8 && fabs(f2) < INFINITY;   // (f2 is NaN if anything in the candidate is not finite)
+        if (!pok) flag_polished = !(fabs(f2) < INFINITY) ? -5 : (!(m_rd <= 1e-8) ? -1 : (!(m_rp <= 1e-10) ? -2 : (!(m_sg <= 1e-8) ? -4 : -3)));
         if (!pok && m_rd <= 1e-8 && attempt < QP_REFINE_ATTEMPTS - 1 && (m_rp > 1e-10 || m_sg > 1e-8)) {
           // single correction of the working set: add the most violated inactive row, else drop the worst wrong-sign row
           double my = 0.0; int myix = -1; double myside = 0.0;

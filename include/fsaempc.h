@@ -91,6 +91,10 @@ int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc,
 typedef struct {
   double* kkt;
   int* polished;
+  const double* x_init;   /* optional INPUT (device, nV per instance; NULL = none): starting point of the interior-point iteration,
+                             clamped to the bounds -- the primal part of what qpOASES' auxInput.x0 / a hot start carries.  Slacks and
+                             multipliers start as always.  Measured on closed-loop QPs (shifted previous plan vs cold):
+                             profiles/round3/warm_start_ab.json */
 } fsaempc_qp_aux;
 
 int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc,

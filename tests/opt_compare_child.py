@@ -13,13 +13,18 @@ sys.path.insert(0, ROOT)
 
 def shapes():
     """(key, model, N) per instantiation: nV = 2N+1 (kinematic) / 2N+4 (dynamic); T = nV // 16 with a border of nV % 16 in
-    1..4, else ceil(nV / 16) without border."""
+    1..4, else ceil(nV / 16) without border -- or, with the slack-border policy of qp_make_dims, the slack columns as the border
+    behind a core padded with dummy variables (the _pad keys)."""
     out = []
     for T in range(1, 13):
         out.append(("T%d_nb1" % T, 0, 8 * T))                       # nV = 16T + 1
         if T <= 10:
             out.append(("T%d_nb4" % T, 1, 8 * T))                   # nV = 16T + 4
-        out.append(("T%d_nb0" % T, 0, 8 * T - 1) if T > 1 else ("T1_nb0", 0, 4))   # nV = 16T - 1 (T = 1: nV = 9)
+        out.append(("T%d_nb0" % T, 0, 8 * T - 1) if T > 1 else ("T1_nb0", 0, 4))   # nV = 16T - 1 (T = 1: nV = 9); solved with the slack-border policy off
+        if T > 1:
+            out.append(("T%d_pad1" % T, 0, 8 * T - 1))              # the same shape with the policy on: slack column as the border, 1 dummy variable
+        if 2 <= T <= 9:
+            out.append(("T%d_pad4" % T, 1, 8 * T - 3))              # nV = 16T - 2, dynamic: 4 slack columns as the border, 6 dummy variables
     return out
 
 
@@ -35,6 +40,7 @@ def main():
     for key, model, N in shapes():
         x0, xl, ul, xr = fm.instances(model, N, 0.05, otr.L, 515, range(B))
         q = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul)
+        os.environ["FSAEMPC_SLACK_BORDER"] = "0" if key.endswith("_nb0") else "1"   # (read by qp_make_dims at every call)
         o = fm.qp_solve_batch_device(*(dev(q[k]) for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")))
         torch.cuda.synchronize()
         res[key + "_fl"] = o["exitflag"].cpu().numpy(); res[key + "_it"] = o["iter"].cpu().numpy(); res[key + "_x"] = o["x"].cpu().numpy()

@@ -85,23 +85,53 @@ def test_00_mfma_layout_selftest(fm):
     assert fm.lib().fsaempc_selftest_mfma() == 0, fm.lib().fsaempc_last_error()
 
 
+def _solver_dims(nV, nC, slack_border=True):
+    """(solver variable count, index of every caller variable in the solver's numbering): the tile / border rule of qp_make_dims
+    (csrc/qp_solver.hip).  nV mod 16 in 1..4: those trailing variables are the border.  Else, for QPs with the row / column
+    signature of the reference's (nC = 10 (nV - 4) dynamic, 3 (nV - 1) kinematic) the trailing slack variables are kept as the
+    border behind a core padded with dummy variables to a multiple of 16."""
+    rem = nV % 16
+    if nV >= 16 and 1 <= rem <= 4:
+        return nV, np.arange(nV)
+    if slack_border and nV >= 20:
+        ns = 4 if (nC == 10 * (nV - 4) and (nV - 4) % 2 == 0) else (1 if (nC == 3 * (nV - 1) and (nV - 1) % 2 == 0) else 0)
+        if ns:
+            T = (nV - ns + 15) // 16
+            return 16 * T + ns, np.concatenate([np.arange(nV - ns), 16 * T + np.arange(ns)])
+    return nV, np.arange(nV)
+
+
+@pytest.mark.parametrize("slack_border", [True, False])
 @pytest.mark.parametrize("model,N", [(0, 12), (0, 8), (0, 40), (1, 8), (1, 7), (0, 9), (1, 40), (0, 38), (1, 38)])
-def test_01_normal_matrix_dump_matches_numpy(fm_dbg, torch_, orc, otrack, model, N):
-    """First iteration internals of instance 0: M = H~ + diag + A~'DA~ (MFMA core + VALU border columns), p1..p3, Hx
-    against numpy.  The cases cover no border (nV mod 16 outside 1..4), 1-, 2-, 3- and 4-column borders."""
+def test_01_normal_matrix_dump_matches_numpy(fm_dbg, torch_, orc, otrack, model, N, slack_border):
+    """First iteration internals of instance 0: M = H~ + diag + A~'DA~ (MFMA core + border columns), p1..p3, Hx against numpy.
+    The cases cover no border, 1-, 2-, 3- and 4-column borders of the plain rule (nV mod 16) and the slack-border policy
+    (dummy-padded core; FSAEMPC_SLACK_BORDER=0 switches it off).  The kernels dump in the solver's numbering."""
     torch = torch_
     fm = fm_dbg
     x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, [1, 2])
     q = orc.build_qp_batch(model, otrack, N, 0.05, x0, xr, xl, ul)
     n, m = q["g"].shape[1], q["lbA"].shape[1]
-    dump = torch.zeros(4 * n * n + 8 * (n + m), dtype=torch.float64, device="cuda")
+    nS, idx = _solver_dims(n, m, slack_border)
+    dump = torch.zeros(4 * nS * nS + 8 * (nS + m), dtype=torch.float64, device="cuda")
+    old_env = os.environ.get("FSAEMPC_SLACK_BORDER")
+    os.environ["FSAEMPC_SLACK_BORDER"] = "1" if slack_border else "0"
     fm.lib().fsaempc_debug_set_dump(C.c_void_p(dump.data_ptr()), 1)
     try:
         _solve_dev(fm, torch, q)
     finally:
         fm.lib().fsaempc_debug_set_dump(None, 0)
+        if old_env is None:
+            del os.environ["FSAEMPC_SLACK_BORDER"]
+        else:
+            os.environ["FSAEMPC_SLACK_BORDER"] = old_env
     d = dump.cpu().numpy()
-    M = d[: n * n].reshape(n, n)
+    Ms = d[: nS * nS].reshape(nS, nS)
+    M = Ms[np.ix_(idx, idx)]
+    dummies = np.setdiff1d(np.arange(nS), idx)
+    if dummies.size:   # dummy variables: decoupled, unit Hessian diagonal, no bounds
+        off = Ms[np.ix_(dummies, idx)]
+        assert np.abs(off).max() == 0.0 and np.allclose(Ms[np.ix_(dummies, dummies)], np.eye(dummies.size), atol=0)
     H, g, A = q["H"][0].T, q["g"][0], q["A"][0].T
     hd = np.diag(H)
     E = np.where(hd > 1e-12, 1 / np.sqrt(np.maximum(hd, 1e-300)), 1 / np.abs(A).max(axis=0))
@@ -123,10 +153,10 @@ def test_01_normal_matrix_dump_matches_numpy(fm_dbg, torch_, orc, otrack, model,
     w1 = np.where(hl, -(zl / tl) * rpl, 0) + np.where(hu, (zu / tu) * rpu, 0)
     w2 = np.where(hl, 1 / tl, 0) - np.where(hu, 1 / tu, 0)
     for k, w in enumerate((w1, w2, zl - zu)):
-        got = d[n * n + k * n: n * n + (k + 1) * n]
+        got = d[nS * nS + k * nS: nS * nS + (k + 1) * nS][idx]
         ref = As.T @ w[n:]
         assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.abs(ref).max()), k
-    assert np.max(np.abs(d[n * n + 3 * n: n * n + 4 * n] - Hs @ x)) <= 1e-11 * max(1.0, np.abs(Hs @ x).max())
+    assert np.max(np.abs(d[nS * nS + 3 * nS: nS * nS + 4 * nS][idx] - Hs @ x)) <= 1e-11 * max(1.0, np.abs(Hs @ x).max())
 
 
 def test_known_answer_qps_through_the_mirror(fm):
@@ -353,6 +383,32 @@ def test_regression_qps_of_earlier_misses(fm, torch_, orc):
         _certify(qq, out)
         xo, fo, flo, ito, lamo = orc.qp_solve(qq["H"][0].T, qq["g"][0], qq["A"][0].T, qq["lb"][0], qq["ub"][0], qq["lbA"][0], qq["ubA"][0])
         assert flo == 0 and abs(out["fval"][0] - fo) <= FVAL_TOL * max(1.0, abs(fo)), (name, out["fval"][0], fo)
+
+
+@pytest.mark.parametrize("model,N", [(0, 40), (1, 60)])
+def test_starting_point_does_not_change_the_answer(fm, torch_, orc, otrack, model, N):
+    """fsaempc_qp_aux.x_init (the primal part of qpOASES' auxInput.x0 / of a hot start): a convex QP has one minimiser, so any
+    starting point -- the solution itself, a perturbed one, garbage outside the bounds, NaN -- must end at the cold solve's point."""
+    torch = torch_
+    B = 32
+    x0, xl, ul, xr = orc.synth_instances(model, N, 0.05, otrack.L, 20190, range(B))
+    q = orc.build_qp_batch(model, otrack, N, 0.05, x0, xr, xl, ul)
+    dq = {k: _dev(torch, q[k]) for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")}
+    args = [dq[k] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")]
+    cold = fm.qp_solve_batch_device(*args, want_lambda=True, want_aux=True)
+    rng = np.random.default_rng(5)
+    xc = cold["x"]
+    starts = dict(solution=xc.clone(), perturbed=xc + 0.05 * torch.from_numpy(rng.standard_normal(tuple(xc.shape))).cuda(),
+                  far=1e3 * torch.from_numpy(rng.standard_normal(tuple(xc.shape))).cuda(), nan=torch.full_like(xc, float("nan")))
+    for name, xi in starts.items():
+        w = fm.qp_solve_batch_device(*args, want_lambda=True, want_aux=True, x_init=xi.contiguous())
+        torch.cuda.synchronize()
+        assert (w["exitflag"] == 0).all(), (name, w["exitflag"])
+        sol = {k: w[k].cpu().numpy() for k in ("x", "lam")}
+        _certify(q, sol)
+        both = ((w["polished"] > 0) & (cold["polished"] > 0)).cpu().numpy()
+        _x_close(sol["x"], xc.cpu().numpy(), both, name)
+        assert np.allclose(w["fval"].cpu().numpy(), cold["fval"].cpu().numpy(), rtol=FVAL_TOL, atol=FVAL_TOL), name
 
 
 def test_sequence_api(fm, orc, otrack):
@@ -701,7 +757,7 @@ def test_shipped_build_matches_O1_build(fm, tmp_path):
         assert r.returncode == 0, (tag, r.stdout[-2000:], r.stderr[-4000:])
         res[tag] = np.load(out)
     keys = sorted(k[:-3] for k in res["O3"].files if k.endswith("_fl"))
-    assert len(keys) == 36, keys            # 12 tile counts x 3 border widths
+    assert len(keys) == 36 + 11 + 8, keys   # 12 tile counts x 3 border widths + the dummy-padded shapes of the slack-border policy
     for k in keys:
         a, b = res["O1"], res["O3"]
         assert np.array_equal(a[k + "_fl"], b[k + "_fl"]), (k, a[k + "_fl"], b[k + "_fl"])

@@ -124,7 +124,7 @@ def test_reports_of_the_built_library():
     logs = sorted(glob.glob(os.path.join(ROOT, "fsae-mpc_amd", "lib", "*.isa.log")))
     names = {os.path.basename(f)[:-8] for f in logs}
     need = {"capi", "ltv_build", "plant", "reference", "qp_solver_tu0", "qp_solver_tu1", "qp_solver_tu2", "qp_solver_tu3", "qp_solver_tu4",
-            "qp_wg_1_5", "qp_wg_6_6", "qp_wg_7_8", "qp_wg_9_10", "qp_wg_11_12"}
+            "qp_wg_1_5", "qp_wg_6_6", "qp_wg_7_7", "qp_wg_8_8", "qp_wg_9_9", "qp_wg_10_10", "qp_wg_11_11", "qp_wg_12_12"}
     assert need <= names, sorted(need - names)
     for f in logs:
         head = open(f).readline()

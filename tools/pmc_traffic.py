@@ -2,7 +2,7 @@
 """Turn the rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs, as MI355X_MICROARCH.md prescribes)
 into the per-launch HBM-side traffic of the dominant kernel.  Corrections of the guide for gfx950: counters are in KB;
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (doubled here); WRITE_SIZE is exact for
-16-B-per-lane streaming stores (taken as is).  usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
+16-B-per-lane streaming stores (taken as is).  usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [kernel-substring]"""
 import csv
 import glob
 import json
@@ -17,7 +17,7 @@ def mean_counter(d, name, kernel):
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
-    kernel = "qp_solve_kernel"
+    kernel = sys.argv[4] if len(sys.argv) > 4 else "qp_solve_kernel"
     fs, nf = mean_counter(fetch_dir, "FETCH_SIZE", kernel)
     wsz, nw = mean_counter(write_dir, "WRITE_SIZE", kernel)
     res = {"kernel": kernel, "launches_averaged": [nf, nw], "FETCH_SIZE_KB_raw": fs, "WRITE_SIZE_KB_raw": wsz,
