@@ -1528,7 +1528,9 @@ template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) voi
     const double fval = wave_sum(fl);
     const double rd_rel = wave_max(m_rd);
     const double gap_rel = gap / fmax(1.0, fabs(fval));
-    const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
+    // (fmax drops NaN operands: an iterate with NaN in it -- a step along a direction from a broken-down factorisation, 0 * NaN --
+    //  would read as merit 0.  Its objective is NaN, and so must the merit be: the best saved iterate is returned then.)
+    const double merit = (fabs(fval) < INFINITY && fabs(gap_rel) < INFINITY) ? fmax(rd_rel, fmax(rp_rel, gap_rel)) : INFINITY;
     fval_s = fval; merit_s = merit;
     const bool res_ok = merit <= P.tol;
 #ifdef QP_DEBUG_DUMP

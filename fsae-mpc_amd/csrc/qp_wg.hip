@@ -164,6 +164,10 @@ DEVINL int diag_factor(int c, int q, v4d& Ud, v4d& Yk, double floor_abs) {
 #define STAMP_DECL unsigned long long st_acc[16]; for (int i_ = 0; i_ < 16; ++i_) st_acc[i_] = 0; unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #define STAMP(id) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[id] += t_ - st_t0; st_t0 = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAMP_OUT do { if (P.dump && P.dump_stage == 9 && tid == 0) for (int i_ = 0; i_ < 16; ++i_) P.dump[(size_t)b * 16 + i_] = (double)st_acc[i_]; } while (0)
+#elif defined(QP_PARANOID)   // diagnostic build only: a workgroup barrier at every phase boundary (hunting a missing one)
+#define STAMP_DECL
+#define STAMP(id) __syncthreads()
+#define STAMP_OUT do { } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(id) do { } while (0)
@@ -997,7 +1001,11 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
       auto run_k = [&](auto Kc, int tr0, int tr1, int tc) AINL {
         constexpr int K = decltype(Kc)::value;
         constexpr int KK = K > 0 ? K : 1;
+#ifdef QP_WG_NOPIPE   // diagnostic builds
+        constexpr bool PIPE = false;
+#else
         constexpr bool PIPE = K <= 5;     // (more tiles: two pairs of operands in registers next to the accumulators would spill)
+#endif
         struct POps { v2d dd, sv, bi[KK], bj[KK], bc[CW]; };
         int bcrec[CW];                    // my column tiles' records in the chunk (record 0 stands in for an inactive one)
         bool side_on[CW];
@@ -1140,7 +1148,9 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
     const double fval = wave_sum(fl);
     const double rd_rel = wave_max(m_rd);
     const double gap_rel = gap / fmax(1.0, fabs(fval));
-    const double merit = fmax(rd_rel, fmax(rp_rel, gap_rel));
+    // (fmax drops NaN operands: an iterate with NaN in it -- a step along a direction from a broken-down factorisation, 0 * NaN --
+    //  would read as merit 0.  Its objective is NaN, and so must the merit be: the best saved iterate is returned then.)
+    const double merit = (fabs(fval) < INFINITY && fabs(gap_rel) < INFINITY) ? fmax(rd_rel, fmax(rp_rel, gap_rel)) : INFINITY;
     fval_s = fval; merit_s = merit;
     const bool res_ok = merit <= P.tol;
     if (!(merit < INFINITY)) { flag = have_saved ? 2 : -1; break; }

@@ -33,6 +33,8 @@ def main():
                                                            # the model's domain, e.g. v_x -> 0 in the dynamic model): the reference's
                                                            # MEX gateway rejects such a call ("Argument contains NaN")
     x0 = cl.x0.cpu().numpy()
+    fin = cl.finished.cpu().numpy()
+    lost_qps = int((~ac[:, fin == 2]).sum())   # steps the lost cars sat out
     print(json.dumps({
         "metric": "QP solves/sec (closed loop, %s N=%d, fp64)" % (a.model, a.horizon), "value": solved / dt_wall, "unit": "QP solves/s",
         "n_gpus": 1, "steps": a.steps, "ms_per_step": 1e3 * dt_wall / a.steps, "dtype": "f64", "data": "synthetic",
@@ -42,6 +44,9 @@ def main():
                    "qps_of_driving_cars": n_act, "qps_total_launched": int(a.batch * a.steps),
                    "exitflag_histogram_driving_cars": hist, "minus1_with_nonfinite_qp_data": bad_data,
                    "minus1_on_finite_qp_data_pct": 100.0 * (hist.get(-1, 0) - bad_data) / max(1, n_act), "abnormal_exit_pct": 100.0 * (1.0 - solved / max(1, n_act)),
+                   # the same tally with the QPs a lost car (|n| >= 3 m, |v| >= 100 m/s or |state| >= 1e6: `finished` = 2, plant.hip) would still
+                   # have launched counted as abnormal: lost cars leave the denominator above, round 1 had no such rule
+                   "abnormal_exit_pct_lost_cars_counted": 100.0 * (1.0 - solved / max(1, n_act + lost_qps)), "qps_not_launched_for_lost_cars": lost_qps,
                    "mean_ipm_iterations": float(it[ac].mean()) if n_act else 0.0,
                    "cars_past_end_of_track_parameter": int((cl.finished == 1).sum().item()), "cars_lost": int((cl.finished == 2).sum().item()),
                    "mean_speed_end": float(cl.cart[:, 3].mean().item()),

@@ -15,7 +15,7 @@ def main():
     tr = fm.Track.load("fsg2019")
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     st = fm.LtvBatch(model, N, 0.05, tr, chunk)
-    tally, its, vert, bad = {}, [], [], []
+    tally, its, vert, bad, nonfin = {}, [], [], [], 0
     for a in range(lo, hi, chunk):
         ids = np.arange(a, a + chunk)
         x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 20190, ids)
@@ -26,9 +26,10 @@ def main():
             tally[int(f)] = tally.get(int(f), 0) + int((fl[:n] == f).sum())
         its.append(o["iter"].cpu().numpy()[:n]); vert.append(o["polished"].cpu().numpy()[:n] > 0)
         bad += [int(i) for i in ids[:n][fl[:n] != 0]]
+        nonfin += int((~torch.isfinite(o["x"][:n]).all(1)).sum().item())   # (a flag-0 instance must never carry a NaN)
     its = np.concatenate(its); vert = np.concatenate(vert)
     print(json.dumps({"shape": "%s N=%d ids %d..%d" % (sys.argv[1], N, lo, hi - 1), "exitflags": tally, "nonzero_ids": bad[:20],
-                      "mean_iter": float(its.mean()), "max_iter": int(its.max()), "on_vertex": float(vert.mean())}))
+                      "mean_iter": float(its.mean()), "max_iter": int(its.max()), "on_vertex": float(vert.mean()), "instances_with_nonfinite_x": nonfin}))
 
 
 if __name__ == "__main__":
