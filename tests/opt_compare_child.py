@@ -40,7 +40,7 @@ def main():
     for key, model, N in shapes():
         x0, xl, ul, xr = fm.instances(model, N, 0.05, otr.L, 515, range(B))
         q = orc.build_qp_batch(model, otr, N, 0.05, x0, xr, xl, ul)
-        os.environ["FSAEMPC_SLACK_BORDER"] = "0" if key.endswith("_nb0") else "1"   # (read by qp_make_dims at every call)
+        os.environ["FSAEMPC_SLACK_BORDER"] = "0" if key.endswith("_nb0") else "2"   # (read by qp_make_dims at every call; 2 = also where it does not pay)
         o = fm.qp_solve_batch_device(*(dev(q[k]) for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")))
         torch.cuda.synchronize()
         res[key + "_fl"] = o["exitflag"].cpu().numpy(); res[key + "_it"] = o["iter"].cpu().numpy(); res[key + "_x"] = o["x"].cpu().numpy()

@@ -28,7 +28,7 @@ def timed(fn):
 
 
 def run(model, N, B, steps, track):
-    cl = ClosedLoop(model, N, 0.05, track, monte_carlo_carts(track, B, 20190))
+    cl = ClosedLoop(model, N, 0.05, track, monte_carlo_carts(track, B, 20190)[0])
     nV = cl.mpc.nV
     prev = None
     rec = dict(cold_it=[], warm_it=[], cold_ms=[], warm_ms=[], cold_ok=0, warm_ok=0, n=0, dx=[])
