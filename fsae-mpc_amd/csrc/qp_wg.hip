@@ -1020,6 +1020,9 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
           for (int t = 0; t < K; ++t) { o.bi[t] = *reinterpret_cast<const v2d*>(&slds[rb + tI[t] * 128]); o.bj[t] = *reinterpret_cast<const v2d*>(&slds[rb + tJ[t] * 128]); }
 #pragma unroll
           for (int ci = 0; ci < CW; ++ci) o.bc[ci] = *reinterpret_cast<const v2d*>(&slds[rb + bcrec[ci]]);
+#ifdef QP_WG_LDWAIT   // diagnostic builds: the reads complete before anything else is issued
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         };
         auto mm = [&](const POps& o) AINL {
 #pragma unroll

@@ -723,6 +723,23 @@ def test_closed_loop_monte_carlo_abnormal_exits(fm, torch_, model):
     assert np.isfinite(cl.cart.cpu().numpy()[(cl.finished == 0).cpu().numpy()]).all()
 
 
+@pytest.mark.parametrize("model", [0, 1])
+def test_closed_loop_warm_start_option(fm, torch_, model):
+    """ClosedLoop(warm_start=True): every solve starts from the previous plan shifted by one stage (fsaempc_qp_aux.x_init through the
+    fused step).  Same QPs, same optimum: the cars end where the cold loop puts them (to the plant's sensitivity), no more abnormal
+    exits, not more iterations."""
+    tr = fm.Track.load("fss2019")
+    cold, fc, ic, ac = fm.monte_carlo(model, 40, tr, 128, 12, seed=20190)
+    warm, fw, iw, aw = fm.monte_carlo(model, 40, tr, 128, 12, seed=20190, warm_start=True)
+    ok = (fc == 0).all(axis=0) & (fw == 0).all(axis=0) & ac[-1] & aw[-1]          # cars that solved every step in both runs
+    assert ok.mean() >= 0.7, ok.mean()
+    a, b = cold.cart.cpu().numpy()[ok], warm.cart.cpu().numpy()[ok]
+    err = np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(a).max(axis=1))
+    assert np.percentile(err, 90) <= 1e-6 and err.max() <= 1e-2, (np.percentile(err, 90), err.max())
+    assert ((fw == 0) & aw).sum() >= 0.98 * ((fc == 0) & ac).sum()
+    assert iw[aw].mean() <= ic[ac].mean() + 0.5, (iw[aw].mean(), ic[ac].mean())
+
+
 @pytest.mark.parametrize("model,N", [(0, 20), (1, 20), (1, 80)])
 def test_sqp_sweeps(fm, torch_, orc, model, N):
     """Re-linearisation sweeps ((1, 80) is BASELINE configs[4]: dynamic N = 80, nV = 164, nC = 1600) against
