@@ -2422,11 +2422,12 @@ static hipError_t qp_wg_launch(const QpParams& P, int batch, hipStream_t st) {
   return hipErrorInvalidValue;
 }
 #endif
+static int prep_thr() { static const char* e = getenv("FSAEMPC_PREP_THR"); return e ? atoi(e) : 256; }   // (A/B runs)
 hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev_mid) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qp_prep_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.d.lds_prep);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(P.d.m > 256 ? 1024 : 256), P.d.lds_prep, st, P);
+  hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(P.d.m > prep_thr() ? 1024 : 256), P.d.lds_prep, st, P);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ev_mid) { e = hipEventRecord(ev_mid, st); if (e != hipSuccess) return e; }

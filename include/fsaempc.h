@@ -122,7 +122,8 @@ int fsaempc_qp_solve_batch(const fsaempc_qp_desc* desc,
  * one QP per call (k columns of g/lb/ub/lbA/ubA => k QPs, as in qpOASES.m:65-67).  The handle owns device copies of H and
  * A (uploaded by 'i' and 'm' only), the solver workspace and the per-call vectors, so a hot start transfers (3 nV + 2 nC) k
  * doubles and the results, nothing else.  Every call is a COLD interior-point solve: same results as a qpOASES hot start, but
- * the previous iterate is not used as a starting point (an interior-point method gains little from it).
+ * the previous iterate is not used as a starting point (measured: 3-10 % fewer iterations per QP, profiles/round3/warm_start_ab.json,
+ * DESIGN.md 6d; fsaempc_qp_aux.x_init of the batched entries takes a starting point for callers that want one).
  * fsaempc_seq_equality is qpOASES_sequence.m:64 ('e'): the equality-constrained QP fixed by the working set of the handle's
  * last 'i'/'h'/'m' solve (first column; a side is in the set iff its multiplier has the side's sign and exceeds the side's
  * slack -- on a refined vertex: iff the multiplier is non-zero); it returns FSAEMPC_ERR_SOLVER when that QP has no solution and
