@@ -1001,8 +1001,10 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
       auto run_k = [&](auto Kc, int tr0, int tr1, int tc) AINL {
         constexpr int K = decltype(Kc)::value;
         constexpr int KK = K > 0 ? K : 1;
-#ifdef QP_WG_NOPIPE   // diagnostic builds
+#ifdef QP_WG_NOPIPE   // diagnostic / guard builds
         constexpr bool PIPE = false;
+#elif defined(QP_WG_NOPIPE_MASK)   // diagnostic builds: bit K set = tile count K takes the unpipelined body
+        constexpr bool PIPE = K <= 5 && !((QP_WG_NOPIPE_MASK >> K) & 1);
 #else
         constexpr bool PIPE = K <= 5;     // (more tiles: two pairs of operands in registers next to the accumulators would spill)
 #endif
