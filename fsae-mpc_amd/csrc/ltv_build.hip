@@ -19,6 +19,7 @@
 namespace {
 
 #define DEVINL __device__ __forceinline__
+typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr double LR = 0.6183, LF = 0.8672;
 constexpr double VM = 280, VI = 200, GRAV = 9.81;
 constexpr double PB = 12.56, PC = 1.38, PD = 1.60, PE = -0.58;
@@ -265,6 +266,7 @@ template <int NX> __global__ __launch_bounds__(256) void ltv_build_kernel(LtvPar
   constexpr int CW = (NX == 5) ? 3 : (2 * 4 + 2 + 4 + 2);  // kin: C3,C4,const ; dyn: slip rows (2x4 coef + 2 const), tyre (4 coef K-part) + 2
   double* red = cc + (size_t)N * CW;     // reduction scratch (nth)
   double* ell = red + nth;               // 24: dac[12], dal[12] of the inscribed 12-gon (dynamic_tyre_linearise_constraints.m:33-39)
+  double* colst = ell + 24;              // one column of Bt (R doubles) per wavefront: stage of step 4c
 
   if (tid < 12) {
     const int j = tid;
@@ -370,60 +372,103 @@ template <int NX> __global__ __launch_bounds__(256) void ltv_build_kernel(LtvPar
       }
     }
   }
-  // ---- 4c. constraint matrix A (nC x nV, column-major); threads sweep rows fastest for coalesced stores ----
-  // (row, col) advance incrementally with e (no integer division per entry); the 12 half-plane directions of the tyre
-  // ellipse come from a small LDS table instead of sin/cos per entry
-  int row = tid % nC, col = tid / nC;
-  for (int e = tid; e < nC * nV; e += nth, row += nth) {
-    while (row >= nC) { row -= nC; ++col; }
-    const double* bcol = Bt + (size_t)col * R;
-    double v = 0.0;
-    if (row < 4 * N) {
-      const int blk = row / N, k = row - blk * N;
-      const int idx = blk == 0 ? vidx : (blk == 1 ? didx : nidx);
-      v = bcol[k * NX + idx];
-      if (col == scol && blk == 2) v = 1.0;
-      if (col == scol && blk == 3) v = -1.0;
-    } else if (NX == 5) {
-      const int blk = (row - 4 * N) / N, k = row - 4 * N - blk * N;
-      const double* ck = cc + (size_t)k * CW;
-      v = ck[0] * bcol[k * NX + 3] + ck[1] * bcol[k * NX + 4];
-      if (col == scol) v = blk == 0 ? 1.0 : -1.0;   // shared slack (quirk C-7)
-    } else if (row < 8 * N) {
-      const int blk = (row - 4 * N) / (2 * N), rr = row - 4 * N - blk * 2 * N, k = rr >> 1, q = rr & 1;
-      const double* ck = cc + (size_t)k * CW;
-      for (int j = 0; j < 4; ++j) v += ck[4 * q + j] * bcol[k * NX + 3 + j];
-      if (col == scol + 1 + q) v = blk == 0 ? 1.0 : -1.0;
-    } else {
-      const int rr = row - 8 * N, k = rr / 12, j = rr - 12 * k;
-      const double* ck = cc + (size_t)k * CW;
-      const double dac = ell[j], dal = ell[12 + j];
-      for (int jj = 0; jj < 3; ++jj) v += dal * ck[10 + jj] * bcol[k * NX + 3 + jj];
-      if (col == 2 * k) v += dac;
-      if (col == scol + 3) v = -1.0;
+  // ---- 4c. constraint matrix A (nC x nV, column-major).  One column at a time per wavefront: the column of Bt (R doubles,
+  // contiguous) is staged in LDS with coalesced loads, then the nC entries of that column of A are formed from it and stored
+  // with coalesced stores.  (Round 2 swept all entries with one thread each and read Bt with stride NX: 4.2 of the 10.3 ms of a
+  // dynamic N = 60 batch.)  The 12 half-plane directions of the tyre ellipse come from a small LDS table. ----
+  {
+    const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6;
+    double* bc = colst + (size_t)wv * R;                     // this wave's column stage
+    for (int col = wv; col < nV; col += nwv) {
+      const bool inp = col < 2 * N;                          // input column: a column of Bt; slack column: unit entries only
+      for (int i = lane; i < R; i += 64) bc[i] = inp ? Bt[(size_t)col * R + i] : 0.0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double* acol = A + (size_t)col * nC;
+      for (int row = lane; row < nC; row += 64) {
+        double v = 0.0;
+        if (row < 4 * N) {
+          const int blk = row / N, k = row - blk * N;
+          const int idx = blk == 0 ? vidx : (blk == 1 ? didx : nidx);
+          v = bc[k * NX + idx];
+          if (col == scol && blk == 2) v = 1.0;
+          if (col == scol && blk == 3) v = -1.0;
+        } else if (NX == 5) {
+          const int blk = (row - 4 * N) / N, k = row - 4 * N - blk * N;
+          const double* ck = cc + (size_t)k * CW;
+          v = ck[0] * bc[k * NX + 3] + ck[1] * bc[k * NX + 4];
+          if (col == scol) v = blk == 0 ? 1.0 : -1.0;   // shared slack (quirk C-7)
+        } else if (row < 8 * N) {
+          const int blk = (row - 4 * N) / (2 * N), rr = row - 4 * N - blk * 2 * N, k = rr >> 1, q = rr & 1;
+          const double* ck = cc + (size_t)k * CW;
+          for (int j = 0; j < 4; ++j) v += ck[4 * q + j] * bc[k * NX + 3 + j];
+          if (col == scol + 1 + q) v = blk == 0 ? 1.0 : -1.0;
+        } else {
+          const int rr = row - 8 * N, k = rr / 12, j = rr - 12 * k;
+          const double* ck = cc + (size_t)k * CW;
+          const double dac = ell[j], dal = ell[12 + j];
+          for (int jj = 0; jj < 3; ++jj) v += dal * ck[10 + jj] * bc[k * NX + 3 + jj];
+          if (col == 2 * k) v += dac;
+          if (col == scol + 3) v = -1.0;
+        }
+        acol[row] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    A[e] = v;
   }
   // ---- 5. H = 2 (Bt' Qbar Bt + Rbar), g = 2 Bt' Qbar r  (generate_qp.m:29-31); only states 1..3 carry weight ----
+  // The input block of H is a SYRK over the 3N weighted rows of Bt: on the matrix cores (v_mfma_f64_16x16x4_f64), one 16 x 16 tile
+  // pair (I >= J) per wavefront at a time, operands gathered from Bt (column-major, just written by this workgroup: L2), k-steps
+  // started at the first block row in which column tile I is non-zero (Bt is block lower-triangular).  (Round 2 computed every
+  // entry as a scalar dot product with stride-NX loads: 3.5 of the 10.3 ms of a dynamic N = 60 batch, 0.95 of 2.26 ms on the
+  // headline shape.)  Lane (c = l & 15, q = l >> 4): A operand = weight * Bt[row rho][16 I + c], B operand = Bt[row rho][16 J + c],
+  // rho = 4 s + q over the weighted rows (k, r) = (rho / 3, rho % 3); result register p holds H[16 I + q + 4 p][16 J + c].
   const double Qw[3] = {5, 250, 2000};   // ltvmpc_*.m:32 ; Q_terminal = 10 Q (:33)
-  for (int e = tid; e < nV * (nV + 1) / 2; e += nth) {
-    // unrank (i >= j) from e
-    int j = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-    while ((j + 1) * (j + 2) / 2 <= e) ++j;
-    while (j * (j + 1) / 2 > e) --j;
-    const int i = j; const int jj = e - j * (j + 1) / 2;   // i >= jj
-    double s = 0.0;
-    if (i < 2 * N) {
-      const double* ci = Bt + (size_t)i * R; const double* cj = Bt + (size_t)jj * R;
-      const int k0 = i >> 1;   // both columns vanish above their block row; i >= jj so start at i's block
-      for (int k = k0; k < N; ++k) {
-        const double wq = (k == N - 1) ? 10.0 : 1.0;
-        for (int r = 0; r < 3; ++r) s += ci[k * NX + r] * (wq * Qw[r]) * cj[k * NX + r];
+  {
+    const int lane = tid & 63, wv = tid >> 6, nwv = nth >> 6, c = lane & 15, q = lane >> 4;
+    const int nU = 2 * N, Tu = (nU + 15) >> 4, npairs = Tu * (Tu + 1) / 2, ksteps = (3 * N + 3) >> 2;
+    for (int pidx = wv; pidx < npairs; pidx += nwv) {
+      int I = 0;
+      while ((I + 1) * (I + 2) / 2 <= pidx) ++I;
+      const int J = pidx - I * (I + 1) / 2;                      // I >= J
+      const int ci = 16 * I + c, cj = 16 * J + c;
+      const double* pi_ = Bt + (size_t)(ci < nU ? ci : 0) * R;
+      const double* pj_ = Bt + (size_t)(cj < nU ? cj : 0) * R;
+      const bool oni = ci < nU, onj = cj < nU;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      const int s0 = (3 * 8 * I) >> 2;                            // column tile I starts at stage 8 I: weighted row 24 I
+      int rho = 4 * s0 + q, k = rho / 3, r = rho - 3 * k;
+      constexpr int UN = 8;                                       // k-steps per round: all 2 UN gathers in flight before the first MFMA
+      for (int s = s0; s < ksteps; s += UN) {
+        double av[UN], bv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const bool on = k < N;                                  // (rows beyond 3N: zero operands; the address stays inside Bt)
+          const int off = (on ? k : 0) * NX + r;
+          const double wq = ((k == N - 1) ? 10.0 : 1.0) * (r == 0 ? Qw[0] : (r == 1 ? Qw[1] : Qw[2]));
+          const double a_ = pi_[off], b_ = pj_[off];
+          av[u] = (on && oni) ? wq * a_ : 0.0;
+          bv[u] = (on && onj) ? b_ : 0.0;
+          rho += 4; ++r; ++k; if (r == 3) { r = 0; ++k; }        // rho + 4 = 3 (k + 1) + (r + 1)
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
       }
-      if (i == jj) s += 10.0;   // R = [10,10] (ltvmpc_*.m:34)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int i = 16 * I + q + 4 * p, j = cj;
+        if (i < nU && j < nU) {
+          const double v = 2.0 * (acc[p] + (i == j ? 10.0 : 0.0));   // R = [10,10] (ltvmpc_*.m:34)
+          H[(size_t)i + (size_t)j * nV] = v;
+          H[(size_t)j + (size_t)i * nV] = v;
+        }
+      }
     }
-    H[(size_t)i + (size_t)jj * nV] = 2 * s;
-    H[(size_t)jj + (size_t)i * nV] = 2 * s;
+    // slack rows / columns of H carry no quadratic cost
+    for (int e = tid; e < NS * nV; e += nth) {
+      const int sc = 2 * N + e / nV, i = e - (e / nV) * nV;
+      H[(size_t)i + (size_t)sc * nV] = 0.0;
+      H[(size_t)sc + (size_t)i * nV] = 0.0;
+    }
   }
   double qc_local = 0.0;
   for (int i = tid; i < nV; i += nth) {
@@ -476,7 +521,8 @@ __global__ void ltv_post_kernel(int nx, int N, int ns, const double* z, const do
 
 size_t ltv_build_lds_bytes(int nx, int N, int threads) {
   const int CW = (nx == 5) ? 3 : 16;
-  return ((size_t)N * nx * nx + (size_t)N * nx * 2 + (size_t)N * nx + (size_t)nx * N + (size_t)N * CW + threads + 24) * sizeof(double);
+  return ((size_t)N * nx * nx + (size_t)N * nx * 2 + (size_t)N * nx + (size_t)nx * N + (size_t)N * CW + threads + 24 +
+          (size_t)(threads / 64) * nx * N) * sizeof(double);   // last term: the per-wavefront column stage of step 4c
 }
 
 hipError_t ltv_build_launch(const LtvParams& P, int batch, hipStream_t st) {
