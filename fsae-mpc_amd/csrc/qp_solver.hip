@@ -204,10 +204,18 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
     int e = 0;
     double rm = 0.0;
     if (r < m) {
-      for (int col = 0; col < n; ++col) {
-        const double a = fabs(Aat(r, col));
-        rm = fmax(rm, a * Esh[col]);
-        if (a != 0.0 && col < ncols) e = col >> 4;
+      // (eight columns of loads in flight: with one load per iteration the loop ran at one memory latency per column, 30 % of
+      //  this kernel on the headline shape)
+      for (int col0 = 0; col0 < n; col0 += 8) {
+        double av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = col0 + u < n ? Aat(r, col0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int col = col0 + u;
+          const double a = fabs(av[u]);
+          if (col < n) { rm = fmax(rm, a * Esh[col]); if (a != 0.0 && col < ncols) e = col >> 4; }
+        }
       }
       cls_sh[r] = e;
       Fr_sh[r] = rm > 1e-12 ? 1.0 / rm : 1.0;
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
         const int tr = s >> 2, tc = tcs_sh[tr];
         if (t < tc && c >= c0 && c < c0 + TW) {
           const int r = perm_sh[4 * s + q];
-          const double v = r >= 0 ? tile[(c - c0) * mp1 + r] * Fs[(s >> 4) * 64 + q * 16 + (s & 15)] : 0.0;
+          const double v = r >= 0 ? tile[(c - c0) * mp1 + r] * Fr_sh[r] : 0.0;   // (row scale from LDS: the owner-layout copy in global memory cost a load latency per k-step)
           Aw[((size_t)aoff_sh[tr] + ((s >> 1) & 1) * tc + t) * 128 + lane * 2 + (s & 1)] = v;
         }
       }
