@@ -267,10 +267,11 @@ def test_alternate_integrators(fm, torch_, orc, model, integ):
         assert torch.equal(q2["H"], q["H"]) and torch.equal(q2["A"], q["A"])
 
 
-@pytest.mark.parametrize("model,N,B", [(0, 40, 512), (0, 20, 128), (1, 40, 96), (1, 60, 24), (1, 80, 16)])
+@pytest.mark.parametrize("model,N,B", [(0, 40, 512), (0, 20, 128), (1, 40, 96), (1, 60, 24), (1, 80, 16), (0, 64, 48)])
 def test_solve_parity_generic_mode(fm, torch_, orc, model, N, B):
     """Identical (H,g,A,bounds) to the oracle and to the HIP solver (generic mode of SURVEY 8d).  (1, 60) is BASELINE
-    configs[2]'s shape, (1, 80) configs[4]'s (nV = 164, nC = 1600: the workgroup kernel)."""
+    configs[2]'s shape, (1, 80) configs[4]'s (nV = 164, nC = 1600: the workgroup kernel); (0, 64): nV = 129 = 8 x 16 + 1, the shape on
+    which the -O1 build of the pipelined pass 1 goes wrong -- the shipped build must not."""
     torch = torch_
     otr = orc.Track.load(fm.tracks._HERE + "/tracks/fsg2019.json")
     x0, xl, ul, xr = fm.instances(model, N, 0.05, otr.L, 20190, range(B))
