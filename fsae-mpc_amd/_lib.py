@@ -25,7 +25,7 @@ class QpOpts(C.Structure):
 
 
 class QpAux(C.Structure):
-    _fields_ = [("kkt", C.c_void_p), ("polished", C.c_void_p), ("x_init", C.c_void_p)]
+    _fields_ = [("kkt", C.c_void_p), ("polished", C.c_void_p), ("x_init", C.c_void_p), ("difficulty", C.c_void_p)]
 
 
 class QpDesc(C.Structure):

@@ -14,7 +14,7 @@ class ClosedLoop:
     back; like the reference (main.m:122-126, 163-175) a car keeps driving after an abnormal solver exit -- on its last good
     plan -- and the exit flags are only tallied.  Cars that completed the lap (s >= L) or left the track keep their state."""
 
-    def __init__(self, model, N, dt, track, cart0, target_vel=20.0, device="cuda:0", options=None, integrator=-1, warm_start=False):
+    def __init__(self, model, N, dt, track, cart0, target_vel=20.0, device="cuda:0", options=None, integrator=-1, warm_start=False, launch_hint=True):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -44,6 +44,10 @@ class ClosedLoop:
         # cold (main.m:117-120 passes no initial guess) and the gain is modest (profiles/round3/warm_start_ab.json)
         self.warm_start = bool(warm_start)
         self._slack = None
+        # launch_hint: the iteration count of each car's previous QP is handed to the solve as the effort estimate behind its launch
+        # order (fsaempc_qp_aux.difficulty: a far better predictor than the library's cold estimate); results do not depend on it
+        self.launch_hint = bool(launch_hint)
+        self._last_iter = None
         self._x_init = torch.zeros((self.B, self.mpc.nV), dtype=torch.float64, device=self.device) if self.warm_start else None
 
     def _stream(self, stream):
@@ -74,9 +78,11 @@ class ClosedLoop:
             x_init[:, 2 * (N - 1): 2 * N].copy_(self.u_opt[:, N - 1, :])
             if self._slack is not None:
                 x_init[:, 2 * N:].copy_(self._slack)
-        out = self.mpc.step(self.x0, self.x_ref, self.x_opt, self.u_opt, stream=stream, x_init=x_init)   # linearised about the previous plan (main.m:121-125)
+        out = self.mpc.step(self.x0, self.x_ref, self.x_opt, self.u_opt, stream=stream, x_init=x_init,
+                            difficulty=self._last_iter if self.launch_hint else None)   # linearised about the previous plan (main.m:121-125)
         if self.warm_start:
             self._slack = out["slack"]
+        self._last_iter = out["iter"]
         P = lambda t: C.c_void_p(t.data_ptr())
         check(lib().fsaempc_cl_accept_batch_device(self.model, self.N, self.B, P(out["x_opt"]), P(out["u_opt"]), P(out["exitflag"]), P(self.x_opt), P(self.u_opt),
                                                    self._stream(stream)), "fsaempc_cl_accept_batch_device")
@@ -103,13 +109,13 @@ def monte_carlo_carts(track, B, seed):
     return cart, s
 
 
-def monte_carlo(model, N, track, B, steps, seed=20190, options=None, device="cuda:0", warm_start=False):
+def monte_carlo(model, N, track, B, steps, seed=20190, options=None, device="cuda:0", warm_start=False, launch_hint=True):
     """Closed-loop Monte-Carlo: B cars from random initial states, `steps` receding-horizon steps, device-resident loop.
     Returns the ClosedLoop and the per-step tallies (exit flags, iteration counts, driving mask), read back once at the end --
     the reference reports exactly this tally as "abnormal exits %" (main.m:209,222)."""
     import torch
     cart0, s_init = monte_carlo_carts(track, B, seed)
-    cl = ClosedLoop(model, N, 0.05, track, cart0, options=options, device=device, warm_start=warm_start)
+    cl = ClosedLoop(model, N, 0.05, track, cart0, options=options, device=device, warm_start=warm_start, launch_hint=launch_hint)
     cl.x_opt[:, :, 0] += torch.from_numpy(s_init).to(cl.device)[:, None]        # start the closest-point search near the car
     cl.x_opt[:, :, 3] += torch.from_numpy(cart0[:, 3]).to(cl.device)[:, None]   # and the first linearisation at its speed
     flags = torch.zeros((steps, B), dtype=torch.int32, device=cl.device)

@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -44,7 +45,7 @@ long long fsaempc_qp_workspace_bytes(const fsaempc_qp_desc* desc) {
   if (!desc || desc->nV <= 0 || desc->nC < 0 || desc->batch < 0) return FSAEMPC_ERR_ARG;
   if (desc->nV > FSAEMPC_MAX_NV) return FSAEMPC_ERR_DIM;
   QpDims d; qp_make_dims(desc->nV, desc->nC, &d);
-  return (long long)(d.ws_per_qp * sizeof(double) * (size_t)(desc->batch > 0 ? desc->batch : 1));
+  return (long long)(d.ws_per_qp * sizeof(double) * (size_t)(desc->batch > 0 ? desc->batch : 1) + qp_order_bytes(desc->batch));
 }
 
 int fsaempc_qp_solve_batch_device(const fsaempc_qp_desc* desc, const double* H, const double* g, const double* A,
@@ -66,12 +67,15 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double*
   fsaempc_qp_opts o; if (opts) o = *opts; else fsaempc_qp_default_opts(&o);
   QpParams P; memset(&P, 0, sizeof(P));
   qp_make_dims(desc->nV, desc->nC, &P.d);
-  if ((long long)(P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
+  const size_t ws_qps = P.d.ws_per_qp * sizeof(double) * (size_t)desc->batch;
+  if ((long long)(ws_qps + qp_order_bytes(desc->batch)) > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
+  const char* no_order = getenv("FSAEMPC_QP_ORDER");   // A/B runs only: FSAEMPC_QP_ORDER=0 solves in index order (read per call)
+  if (qp_order_bytes(desc->batch) && !(no_order && no_order[0] == '0')) { P.score = (int*)((char*)workspace + ws_qps); P.order = P.score + desc->batch; }
   const bool wg = !qp_runs_wavefront_kernel(P.d);
   if ((wg ? P.d.lds_wg : P.d.lds_solve) > 160 * 1024 || P.d.lds_prep > 160 * 1024) return fail(FSAEMPC_ERR_DIM, "problem exceeds the 160 KiB LDS budget of the kernels");
   P.H = H; P.g = g; P.A = A; P.lb = lb; P.ub = ub; P.lbA = lbA; P.ubA = ubA;
   P.ws = (double*)workspace; P.x = x; P.fval = fval; P.lambda = lambda; P.exitflag = exitflag; P.iter = iter;
-  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr; P.x_init = aux ? aux->x_init : nullptr;
+  P.tol = o.tol; P.tol_loose = o.tol_loose; P.tol_x = o.tol_x; P.inf_bound = o.inf_bound; P.max_iter = o.max_iter; P.polish = o.polish; P.polished = aux ? aux->polished : nullptr; P.kkt = aux ? aux->kkt : nullptr; P.x_init = aux ? aux->x_init : nullptr; P.score_in = aux ? aux->difficulty : nullptr;
   P.shared_HA = desc->shared_HA;
   { const int st = g_dump_stage.load(); P.dump = g_dump.load(); P.dump_stage = st & 0xff; P.dump_iter = st >> 8; }
   const bool timing = g_timing.load();

@@ -49,7 +49,16 @@ struct QpParams {
   double* dump; int dump_stage, dump_iter;
   const double* x_init;   // optional starting point, batch x nu in the caller's variables (null: x = clamp(0, lb, ub)); clamped to the bounds.
                           // Slacks and multipliers start as always (profiles/round3/warm_start_ab.json: what that is worth)
+  int* score;             // optional, batch ints behind the per-QP workspaces: difficulty estimate written by the prep kernel (rows and bounds
+                          // that exclude x = 0: the best cheap predictor of the iteration count found, profiles/round3/launch_order.txt)
+  const int* score_in;    // optional: the caller's difficulty estimate (fsaempc_qp_aux.difficulty) instead of the prep kernel's own
+  int* order;             // optional, batch ints: workgroup -> instance, hardest-looking first (qp_order_kernel).  One wavefront / workgroup
+                          // per QP is dispatched in index order, so a batch ends with its last-started instances: starting the long ones
+                          // first shortens that tail.  Null: identity.  Results do not depend on it (every QP is solved on its own)
 };
+// launch order: batches of more than QP_ORDER_MIN_BATCH instances are solved hardest-looking first
+#define QP_ORDER_MIN_BATCH 256
+inline size_t qp_order_bytes(int batch) { return batch > QP_ORDER_MIN_BATCH ? (((size_t)2 * batch * sizeof(int)) + 255) & ~(size_t)255 : 0; }
 
 void qp_make_dims(int n, int m, QpDims* d);
 // solver index -> caller's variable index (-1: dummy padding variable), and back

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
   for (int tr = tid; tr <= ntr; tr += NTH) { aoff_g[tr] = aoff_sh[tr]; if (tr < ntr) tcs_g[tr] = tcs_sh[tr]; }
 
   // ---- row scaling F_r = 1/max_j |A[r][j] E_j| ; rows handled in owner layout, one slot per wavefront and trip ----
+  int nexcl = 0;   // rows / bounds that exclude x = 0: the difficulty estimate behind the launch order (QpParams::order)
   for (int js = w; js < J; js += NW) {
     const int s = 16 * js + c, pp = 4 * s + q;
     const int r = (s < 4 * ntr) ? perm_sh[pp] : -1;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
     if (valid) {
       double lr = P.lbA[(size_t)b * m + r], ur = P.ubA[(size_t)b * m + r];
       bad |= (lr != lr) || (ur != ur);
+      nexcl += (lr > 0.0) || (ur < 0.0);
       l = lr > -P.inf_bound ? lr * f : -INFINITY;
       u = ur < P.inf_bound ? ur * f : INFINITY;
     }
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
     if (ui >= 0) {
       double lr = P.lb[(size_t)b * nu + ui], ur = P.ub[(size_t)b * nu + ui];
       bad |= (lr != lr) || (ur != ur);
+      nexcl += (lr > 0.0) || (ur < 0.0);
       l = lr > -P.inf_bound ? lr / Esh[i] : -INFINITY;
       u = ur < P.inf_bound ? ur / Esh[i] : INFINITY;
     }
@@ -341,6 +344,66 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
   }
   bad = __syncthreads_or(bad);
   if (tid == 0) ws[d.off_bad] = bad ? 1.0 : 0.0;
+  if (P.score) {
+    __shared__ int score_sh;
+    if (tid == 0) score_sh = 0;
+    __syncthreads();
+    if (nexcl) atomicAdd(&score_sh, nexcl);
+    __syncthreads();
+    if (tid == 0) P.score[b] = P.score_in ? P.score_in[b] : score_sh;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// qp_order_kernel: order[] = instance ids by descending score, ties in index order (a stable counting sort by one workgroup:
+// scores clipped to 1023; eight wavefronts each count and place a contiguous range of the ids, no atomics, so the order -- and
+// with it the timing of a batch -- is the same every run)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void qp_order_kernel(const int* __restrict__ score, int* __restrict__ order, int batch) {
+  constexpr int NBIN = 1024, NWV = 8;
+  __shared__ int cnt[NWV][NBIN], scan[NBIN];
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < NWV * NBIN; e += 1024) (&cnt[0][0])[e] = 0;
+  __syncthreads();
+  const int per = ((batch + NWV - 1) / NWV + 63) & ~63;   // ids per counting wavefront, a multiple of 64
+  const int lo = w * per, hi = min(batch, lo + per);
+  auto bin = [&](int i) { return NBIN - 1 - min(max(score[i], 0), NBIN - 1); };   // bin 0 = highest score
+  // rank of this lane among the lanes of its wavefront holding the same bin (lower lanes first), and that group's size
+  auto group = [&](int k, bool on, int& rank, int& size) {
+    rank = 0; size = 0;
+    for (int l = 0; l < 64; ++l) {
+      const int kl = __shfl(on ? k : -1, l);
+      rank += (kl == k && l < lane); size += (kl == k);
+    }
+  };
+  if (w < NWV)
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+      const int i = i0 + lane; const bool on = i < hi; const int k = on ? bin(i) : 0;
+      int rank, size; group(k, on, rank, size);
+      if (on && rank == 0) cnt[w][k] += size;
+    }
+  __syncthreads();
+  int v = 0;
+  for (int ww = 0; ww < NWV; ++ww) v += cnt[ww][tid];
+  scan[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < NBIN; o <<= 1) {
+    const int a = tid >= o ? scan[tid - o] : 0;
+    __syncthreads();
+    scan[tid] += a;
+    __syncthreads();
+  }
+  int run = scan[tid] - v;   // start of bin tid; then the start of each wavefront's share of it
+  for (int ww = 0; ww < NWV; ++ww) { const int c = cnt[ww][tid]; cnt[ww][tid] = run; run += c; }
+  __syncthreads();
+  if (w < NWV)
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+      const int i = i0 + lane; const bool on = i < hi; const int k = on ? bin(i) : 0;
+      int rank, size; group(k, on, rank, size);
+      int base = on ? cnt[w][k] : 0;
+      if (on) order[base + rank] = i;
+      if (on && rank == 0) cnt[w][k] = base + size;   // (one writer per bin and round; read above by every lane of the group first)
+    }
 }
 
 #endif  // QP_MAIN_TU
@@ -1113,7 +1176,7 @@ template <int T, int NS> DEVINL void rhs_store(const Ctx& k, const v4d* rh, doub
 #define QP_WAVES_PER_SIMD 1
 #endif
 template <int T, int NB> __global__ __launch_bounds__(64, QP_WAVES_PER_SIMD) void qp_solve_kernel(QpParams P) {
-  const int b = blockIdx.x;
+  const int b = P.order ? P.order[blockIdx.x] : blockIdx.x;   // launch order: hardest-looking instances first
   Ctx k;
   const QpDims& d = P.d;
   k.n = d.n; k.m = d.m; k.T = T; k.Kq = d.Kq; k.J = d.J; k.JB = d.JB; k.JT = d.J + d.JB; k.np = d.np; k.ld = 0;
@@ -2438,6 +2501,11 @@ hipError_t qp_launch(const QpParams& P, int batch, hipStream_t st, hipEvent_t ev
   hipLaunchKernelGGL(qp_prep_kernel, dim3(batch), dim3(P.d.m > prep_thr() ? 1024 : 256), P.d.lds_prep, st, P);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (P.order) {
+    hipLaunchKernelGGL(qp_order_kernel, dim3(1), dim3(1024), 0, st, P.score, P.order, batch);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   if (ev_mid) { e = hipEventRecord(ev_mid, st); if (e != hipSuccess) return e; }
 #ifdef QP_PROBE
   if (P.dump && P.dump_stage == 7 && P.d.T == 5) {

@@ -195,7 +195,7 @@ template <int T, int NB, int W> __global__ __launch_bounds__(64 * W, W >= 8 ? 2 
   constexpr int NTH = 64 * W;
   constexpr int NS = 2 + NB;                    // right-hand-side columns riding along the factorisation
   constexpr int V_HB0 = V_MB0 + NB, V_DV = V_MB0 + 2 * NB, V_W1V = V_DV + 1, V_W2V = V_DV + 2, V_LV = V_DV + 3, V_NARR = V_DV + 4;
-  const int b = blockIdx.x;
+  const int b = P.order ? P.order[blockIdx.x] : blockIdx.x;   // launch order: hardest-looking instances first
   const QpDims& d = P.d;
   const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

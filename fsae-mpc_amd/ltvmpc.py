@@ -54,10 +54,11 @@ class LtvBatch:
         check(rc, "fsaempc_ltv_build_qp_batch_device")
         return q
 
-    def step(self, x0, x_ref, x_lin, u_lin, stream=None, want_aux=False, x_init=None):
+    def step(self, x0, x_ref, x_lin, u_lin, stream=None, want_aux=False, x_init=None, difficulty=None):
         """Fused step.  Returns dict(u_opt (B,2N), x_opt (B,nx*N), slack (B,ns), fval, exitflag, iter); want_aux adds the solve's
         per-instance diagnostics `kkt` (achieved relative KKT residual) and `polished` (> 0: the returned point is the vertex); x_init
-        (batch, nV): optional starting point of the interior-point solve (fsaempc_qp_aux.x_init)."""
+        (batch, nV): optional starting point of the interior-point solve (fsaempc_qp_aux.x_init); difficulty (batch,) int32: optional
+        effort estimate per instance for the launch order (fsaempc_qp_aux.difficulty)."""
         torch = self.torch
         B = self.batch
         need = lib().fsaempc_ltv_workspace_bytes(C.byref(self.desc))
@@ -74,7 +75,10 @@ class LtvBatch:
         if x_init is not None and (x_init.dtype != torch.float64 or not x_init.is_contiguous() or tuple(x_init.shape) != (B, self.nV)):
             raise ValueError("x_init must be a contiguous float64 (batch, nV) tensor on the GPU")
         xi = P(x_init) if x_init is not None else None   # starting point of the solve in the QP's variables [u (2N); slacks]
-        aux = QpAux(P(out["kkt"]), P(out["polished"]), xi) if want_aux else QpAux(None, None, xi)
+        if difficulty is not None and (difficulty.dtype != torch.int32 or not difficulty.is_contiguous() or tuple(difficulty.shape) != (B,)):
+            raise ValueError("difficulty must be a contiguous int32 (batch,) tensor on the GPU")
+        df = P(difficulty) if difficulty is not None else None
+        aux = QpAux(P(out["kkt"]), P(out["polished"]), xi, df) if want_aux else QpAux(None, None, xi, df)
         rc = lib().fsaempc_ltv_step_batch_device_aux(C.byref(self.desc), C.byref(self.sp), P(x0), P(x_ref), P(x_lin), P(u_lin), C.byref(self.opts),
                                                      P(out["u_opt"]), P(out["x_opt"]), P(out["slack"]), P(out["fval"]), P(out["exitflag"]), P(out["iter"]),
                                                      C.byref(aux), P(self._ws), C.c_longlong(self._ws.numel() * 8), self._stream(stream))

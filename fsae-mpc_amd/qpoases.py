@@ -78,7 +78,7 @@ def qpOASES(H, g, *args, options=None):
 
 
 def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=False, workspace=None, stream=None,
-                          shared_HA=False, want_aux=False, x_init=None):
+                          shared_HA=False, want_aux=False, x_init=None, difficulty=None):
     """Device-resident batched solve on torch CUDA(HIP) tensors (instance-major, each instance column-major):
     H (B,nV,nV), g (B,nV), A (B,nV,nC) [memory of a column-major nC x nV matrix], lb/ub (B,nV), lbA/ubA (B,nC).
     Asynchronous on `stream` (default: torch's current stream).  Returns dict of device tensors; want_aux adds `kkt`
@@ -109,7 +109,9 @@ def qp_solve_batch_device(H, g, A, lb, ub, lbA, ubA, options=None, want_lambda=F
     pol = torch.empty(B, dtype=torch.int32, device=dev) if want_aux else None
     if x_init is not None and (x_init.dtype != torch.float64 or not x_init.is_contiguous() or not x_init.is_cuda or tuple(x_init.shape) != (B, nV)):
         raise ValueError("x_init must be a contiguous float64 (B, nV) tensor on the GPU")
-    aux = QpAux(P(kkt), P(pol), P(x_init))   # per-instance diagnostics (the analogue of qpOASES' auxOutput) + optional starting point
+    if difficulty is not None and (difficulty.dtype != torch.int32 or not difficulty.is_contiguous() or not difficulty.is_cuda or tuple(difficulty.shape) != (B,)):
+        raise ValueError("difficulty must be a contiguous int32 (B,) tensor on the GPU")
+    aux = QpAux(P(kkt), P(pol), P(x_init), P(difficulty))   # per-instance diagnostics (the analogue of qpOASES' auxOutput) + optional starting point
     rc = lib().fsaempc_qp_solve_batch_device_aux(C.byref(desc), P(H), P(g), P(A), P(lb), P(ub), P(lbA), P(ubA), C.byref(opts),
                                                  P(x), P(fval), P(flag), P(it), P(lam), C.byref(aux), P(workspace),
                                                  C.c_longlong(workspace.numel() * 8), C.c_void_p(st))

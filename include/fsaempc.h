@@ -95,6 +95,12 @@ typedef struct {
                              clamped to the bounds -- the primal part of what qpOASES' auxInput.x0 / a hot start carries.  Slacks and
                              multipliers start as always.  Measured on closed-loop QPs (shifted previous plan vs cold):
                              profiles/round3/warm_start_ab.json */
+  const int* difficulty;  /* optional INPUT (device, one int per instance; NULL = none): the caller's estimate of each instance's solve
+                             effort, any monotone measure -- e.g. the iteration count of the same car's QP one MPC period earlier.
+                             Batches of more than 256 instances are launched hardest-looking first (one wavefront / workgroup per
+                             QP is dispatched in order, so a batch ends with its last-started instances); without this array the
+                             library ranks by the number of rows and bounds that exclude x = 0.  Only the launch order depends on it,
+                             never a result (profiles/round3/launch_order.txt) */
 } fsaempc_qp_aux;
 
 int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc,

@@ -35,7 +35,7 @@ def test_default_opts_and_dims():
 
 def test_struct_layouts_of_the_python_mirror_match_the_header(tmp_path):
     """The ctypes structures of fsae-mpc_amd/_lib.py against include/fsaempc.h: sizes and member offsets as the C compiler sees them
-    (a field added to one side only -- fsaempc_qp_aux.x_init came in round 3 -- would silently shift every later member)."""
+    (a field added to one side only -- fsaempc_qp_aux.x_init and .difficulty came in round 3 -- would silently shift every later member)."""
     import subprocess, ctypes as C
     from fsae_mpc_amd import _lib
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -45,7 +45,7 @@ def test_struct_layouts_of_the_python_mirror_match_the_header(tmp_path):
 #include <stddef.h>
 #include "fsaempc.h"
 int main(void) {
-  printf("aux %zu %zu %zu %zu\\n", sizeof(fsaempc_qp_aux), offsetof(fsaempc_qp_aux, kkt), offsetof(fsaempc_qp_aux, polished), offsetof(fsaempc_qp_aux, x_init));
+  printf("aux %zu %zu %zu %zu %zu\\n", sizeof(fsaempc_qp_aux), offsetof(fsaempc_qp_aux, kkt), offsetof(fsaempc_qp_aux, polished), offsetof(fsaempc_qp_aux, x_init), offsetof(fsaempc_qp_aux, difficulty));
   printf("desc %zu %zu %zu %zu %zu\\n", sizeof(fsaempc_qp_desc), offsetof(fsaempc_qp_desc, nV), offsetof(fsaempc_qp_desc, nC), offsetof(fsaempc_qp_desc, batch), offsetof(fsaempc_qp_desc, shared_HA));
   printf("opts %zu %zu %zu\\n", sizeof(fsaempc_qp_opts), offsetof(fsaempc_qp_opts, max_iter), offsetof(fsaempc_qp_opts, polish));
   return 0;
@@ -55,7 +55,7 @@ int main(void) {
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     out = dict((l.split()[0], [int(v) for v in l.split()[1:]]) for l in subprocess.check_output([str(exe)], text=True).splitlines())
     A, D = _lib.QpAux, _lib.QpDesc
-    assert out["aux"] == [C.sizeof(A), A.kkt.offset, A.polished.offset, A.x_init.offset], out["aux"]
+    assert out["aux"] == [C.sizeof(A), A.kkt.offset, A.polished.offset, A.x_init.offset, A.difficulty.offset], out["aux"]
     assert out["desc"] == [C.sizeof(D), D.nV.offset, D.nC.offset, D.batch.offset, D.shared_HA.offset], out["desc"]
     O = type(_lib.default_opts()) if hasattr(_lib, "default_opts") else None
     if O is not None:

@@ -383,6 +383,50 @@ def test_full_size_config2_properties(fm, torch_, orc):
     assert torch.equal(c["x"], a["x"][sl])
 
 
+@pytest.mark.parametrize("model,N,B", [(0, 40, 1536), (1, 60, 300)])
+def test_launch_order_is_a_stable_sort_and_changes_nothing(fm, torch_, model, N, B):
+    """Batches of more than 256 instances are solved hardest-looking first (qp_solver.h QpParams::order; both solve kernels).
+    The order the library made (tail of the workspace: batch scores, batch ids) must be the stable descending sort of the
+    scores, the scores the number of rows / bounds that exclude x = 0, and every output bit-identical to the solve in index
+    order (FSAEMPC_QP_ORDER=0)."""
+    torch = torch_
+    tr = fm.Track.load("fsg2019")
+    x0, xl, ul, xr = fm.instances(model, N, 0.05, tr.L, 20190, range(B))
+    q = fm.LtvBatch(model, N, 0.05, tr, B).build_qp(_dev(torch, x0), _dev(torch, xr), _dev(torch, xl), _dev(torch, ul))
+    args = [q[k] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")]
+    a = fm.qp_solve_batch_device(*args, want_lambda=True, want_aux=True)
+    torch.cuda.synchronize()
+    tail = a["workspace"].view(torch.int32)[-2 * B - 64:].cpu().numpy()   # the order region is padded to 256 bytes
+    want_score = (((q["lbA"] > 0) | (q["ubA"] < 0)).sum(1) + ((q["lb"] > 0) | (q["ub"] < 0)).sum(1)).cpu().numpy()
+    want_order = np.argsort(-np.minimum(want_score, 1023), kind="stable")
+    found = False
+    for pad in range(0, 65):             # (2 B ints rounded up to 256 bytes: at most 63 ints of padding)
+        sc = tail[len(tail) - 2 * B - pad: len(tail) - B - pad]
+        od = tail[len(tail) - B - pad: len(tail) - pad]
+        if np.array_equal(sc, want_score) and np.array_equal(od, want_order):
+            found = True
+            break
+    assert found, "score / order arrays not found behind the per-QP workspaces"
+    assert len(np.unique(want_score)) > 4     # the test means something: the batch is not one big tie
+    os.environ["FSAEMPC_QP_ORDER"] = "0"
+    try:
+        b = fm.qp_solve_batch_device(*args, want_lambda=True, want_aux=True)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["FSAEMPC_QP_ORDER"]
+    for k in ("x", "fval", "exitflag", "iter", "lam", "kkt", "polished"):
+        assert torch.equal(a[k], b[k]), k
+    assert (a["exitflag"] == 0).all().item()
+    # the caller's own estimate (fsaempc_qp_aux.difficulty) replaces the library's: here the true iteration counts
+    c = fm.qp_solve_batch_device(*args, want_lambda=True, want_aux=True, difficulty=a["iter"])
+    torch.cuda.synchronize()
+    od = c["workspace"].view(torch.int32)[-B - 64:].cpu().numpy()
+    want = np.argsort(-a["iter"].cpu().numpy(), kind="stable")
+    assert any(np.array_equal(od[len(od) - B - pad: len(od) - pad], want) for pad in range(0, 65))
+    for k in ("x", "fval", "exitflag", "iter", "lam", "kkt", "polished"):
+        assert torch.equal(a[k], c[k]), k
+
+
 def test_regression_qps_of_earlier_misses(fm, torch_, orc):
     """QPs an earlier build missed (round 2: exit flag -1 while the oracle solves them; the cause was the accuracy of the
     block rows of the register Cholesky): kinematic N = 40 instance 6585 of the synthetic family and the

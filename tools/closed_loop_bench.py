@@ -19,13 +19,14 @@ def main():
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--seed", type=int, default=20190)
     ap.add_argument("--max-iter", type=int, default=100, help="interior-point iteration limit (bounds the batch tail)")
+    ap.add_argument("--no-launch-hint", action="store_true", help="do not hand the previous iteration counts to the solve as its launch-order estimate (A/B)")
     ap.add_argument("--warm", action="store_true", help="start every solve from the previous plan shifted by one stage (ClosedLoop(warm_start=True))")
     a = ap.parse_args()
     model = fm.KINEMATIC if a.model == "kinematic" else fm.DYNAMIC
     tr = fm.Track.load("fss2019")
     fm.monte_carlo(model, a.horizon, tr, min(a.batch, 64), 2, a.seed, warm_start=a.warm)          # warm-up (allocations, code load)
     t0 = time.perf_counter()
-    cl, fl, it, ac = fm.monte_carlo(model, a.horizon, tr, a.batch, a.steps, a.seed, options=fm.default_opts(max_iter=a.max_iter), warm_start=a.warm)
+    cl, fl, it, ac = fm.monte_carlo(model, a.horizon, tr, a.batch, a.steps, a.seed, options=fm.default_opts(max_iter=a.max_iter), warm_start=a.warm, launch_hint=not a.no_launch_hint)
     dt_wall = time.perf_counter() - t0
     n_act = int(ac.sum())
     hist = {int(k_): int(c_) for k_, c_ in zip(*np.unique(fl[ac], return_counts=True))}
@@ -51,7 +52,7 @@ def main():
                    "mean_ipm_iterations": float(it[ac].mean()) if n_act else 0.0,
                    "cars_past_end_of_track_parameter": int((cl.finished == 1).sum().item()), "cars_lost": int((cl.finished == 2).sum().item()),
                    "mean_speed_end": float(cl.cart[:, 3].mean().item()),
-                   "median_abs_lateral_offset_end": float(np.nanmedian(np.abs(x0[:, 1]))), "seed": a.seed, "max_iter": a.max_iter, "warm_start": bool(a.warm)}}))
+                   "median_abs_lateral_offset_end": float(np.nanmedian(np.abs(x0[:, 1]))), "seed": a.seed, "max_iter": a.max_iter, "warm_start": bool(a.warm), "launch_hint": not a.no_launch_hint}}))
 
 
 if __name__ == "__main__":
