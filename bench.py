@@ -150,6 +150,14 @@ def main():
     torch.cuda.synchronize(dev)
     t_fused = time.perf_counter() - tf0
     fused_rate = float((fo["exitflag"] == 0).sum().item()) * max(2, min(args.steps, 5)) / t_fused
+    # the fused step's four phases by HIP events on the launch stream (one more step, outside every timed region)
+    L.fsaempc_qp_set_timing(1)
+    stepper.step(fx0, fxr, fxl, ful)
+    ph = [C.c_double(0) for _ in range(4)]
+    fused_phases = None
+    if L.fsaempc_ltv_get_timing(*[C.byref(p_) for p_ in ph]) == 0:
+        fused_phases = dict(zip(("build", "prep", "solve", "post"), (round(p_.value, 4) for p_ in ph)))
+    L.fsaempc_qp_set_timing(0)
     if os.environ.get("FSAEMPC_BENCH_DEBUG"):
         print("fused: %.2f ms per step, solved %d" % (1e3 * t_fused / max(2, min(args.steps, 5)), int((fo["exitflag"] == 0).sum().item())), file=sys.stderr)
     mean_it = float(iters.mean())
@@ -205,7 +213,7 @@ def main():
                    "tol_kkt": TOL_KKT, "kkt_reported_by_kernel_max_rank0": float(kkt_dev[flags == 0].max()) if (flags == 0).any() else None,
                    "on_vertex_fraction_rank0": float((polished > 0).mean()),
                    "prep_kernel_ms": float(np.mean(prep_ms)), "solve_kernel_ms": k_ms,
-                   "fused_mode_qp_per_s_rank0": fused_rate,
+                   "fused_mode_qp_per_s_rank0": fused_rate, "fused_mode_phase_ms_rank0": fused_phases,
                    "iteration_histogram_rank0": it_hist, "exitflag_histogram_rank0": fl_hist,
                    "max_rel_kkt_rank0": {"stationarity": kkt_max[0], "primal": kkt_max[1], "complementarity": kkt_max[2]},
                    "exitflag0_per_rank": solved_per_rank,

@@ -11,7 +11,7 @@ EXPORTS = [
     "fsaempc_qp_default_opts", "fsaempc_qp_workspace_bytes", "fsaempc_qp_solve_batch_device", "fsaempc_qp_solve_batch",
     "fsaempc_ltv_nx", "fsaempc_ltv_nV", "fsaempc_ltv_nC", "fsaempc_ltv_build_qp_batch_device",
     "fsaempc_ltv_workspace_bytes", "fsaempc_ltv_step_batch_device", "fsaempc_ltv_step_batch_device_aux", "fsaempc_last_error", "fsaempc_selftest_mfma",
-    "fsaempc_debug_set_dump", "fsaempc_qp_solve_batch_device_aux", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing",
+    "fsaempc_debug_set_dump", "fsaempc_qp_solve_batch_device_aux", "fsaempc_qp_set_timing", "fsaempc_qp_get_timing", "fsaempc_ltv_get_timing",
     "fsaempc_seq_init", "fsaempc_seq_hotstart", "fsaempc_seq_hotstart_matrices", "fsaempc_seq_equality", "fsaempc_seq_cleanup",
     "fsaempc_obtain_reference_batch_device", "fsaempc_reference_live_batch_device",
     "fsaempc_cl_pre_batch_device", "fsaempc_cl_plant_batch_device", "fsaempc_cl_accept_batch_device",

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <dlfcn.h>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -22,6 +23,29 @@ thread_local char g_err[512] = "";
 // per-thread, so timing figures are only meaningful when a single thread launches solves.
 std::atomic<double*> g_dump{nullptr}; std::atomic<int> g_dump_stage{0};
 std::atomic<bool> g_timing{false}; hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+hipEvent_t g_evf[2] = {nullptr, nullptr};   // fused step: before the construction kernel, after the post-solve kernel
+
+// roctx ranges around the launches of every phase (rocprofv3 --marker-trace shows them next to the kernel trace).  The roctx library is
+// looked up at run time: without it (or with FSAEMPC_ROCTX=0) the ranges are no-ops and the library has no dependency on it.
+struct Roctx {
+  int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+  Roctx() {
+    const char* off = getenv("FSAEMPC_ROCTX");
+    if (off && off[0] == '0') return;
+    void* h = nullptr;   // rocprofv3 listens to the rocprofiler-sdk flavour; libroctx64 is roctracer's (rocprof v1 / v2)
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+      if ((h = dlopen(name, RTLD_LAZY | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+struct Range {   // RAII: one named range on the calling thread
+  static Roctx& api() { static Roctx r; return r; }
+  bool on;
+  explicit Range(const char* name) : on(api().push != nullptr) { if (on) api().push(name); }
+  ~Range() { if (on) api().pop(); }
+};
 
 int fail(int code, const char* fmt, const char* a = "") { snprintf(g_err, sizeof(g_err), fmt, a); return code; }
 int hipfail(hipError_t e, const char* where) {
@@ -81,7 +105,8 @@ int fsaempc_qp_solve_batch_device_aux(const fsaempc_qp_desc* desc, const double*
   const bool timing = g_timing.load();
   hipError_t e;
   if (timing) { e = hipEventRecord(g_ev[0], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
-  e = qp_launch(P, desc->batch, (hipStream_t)stream, timing ? g_ev[1] : nullptr);
+  { Range r("fsaempc.qp.prep+solve");   // (prep, order and solve kernels are enqueued by one call; the kernel trace separates them)
+    e = qp_launch(P, desc->batch, (hipStream_t)stream, timing ? g_ev[1] : nullptr); }
   if (e != hipSuccess) return hipfail(e, "qp_launch");
   if (timing) { e = hipEventRecord(g_ev[2], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
   return 0;
@@ -375,16 +400,23 @@ int fsaempc_ltv_step_batch_device_aux(const fsaempc_ltv_desc* desc, const fsaemp
   if ((long long)c.total > workspace_bytes) return fail(FSAEMPC_ERR_WORKSPACE, "workspace too small");
   char* w = (char*)workspace;
   auto D = [&](size_t off) { return (double*)(w + off); };
-  rc = fsaempc_ltv_build_qp_batch_device(desc, sp, x0, x_ref, x_lin, u_lin, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA),
-                                         D(c.pred), D(c.Bt), D(c.qc), stream);
+  Range whole("fsaempc.ltv.step");
+  const bool timing = g_timing.load();
+  if (timing) { hipError_t e = hipEventRecord(g_evf[0], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
+  { Range r("fsaempc.ltv.build");
+    rc = fsaempc_ltv_build_qp_batch_device(desc, sp, x0, x_ref, x_lin, u_lin, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA),
+                                           D(c.pred), D(c.Bt), D(c.qc), stream); }
   if (rc) return rc;
   fsaempc_qp_desc q{fsaempc_ltv_nV(desc->model, desc->N), fsaempc_ltv_nC(desc->model, desc->N), desc->batch, 0};
   rc = fsaempc_qp_solve_batch_device_aux(&q, D(c.H), D(c.g), D(c.A), D(c.lb), D(c.ub), D(c.lbA), D(c.ubA), opts, D(c.z), fval, exitflag, iter,
                                          nullptr, aux, w + c.qpws, (long long)(c.total - c.qpws), stream);
   if (rc) return rc;
-  hipError_t e = ltv_post_launch(fsaempc_ltv_nx(desc->model), desc->N, ltv_ns(desc->model), desc->batch, D(c.z), D(c.pred), D(c.Bt), D(c.qc),
-                                 u_opt, x_opt, slack, fval, (hipStream_t)stream);
+  hipError_t e;
+  { Range r("fsaempc.ltv.post");
+    e = ltv_post_launch(fsaempc_ltv_nx(desc->model), desc->N, ltv_ns(desc->model), desc->batch, D(c.z), D(c.pred), D(c.Bt), D(c.qc),
+                        u_opt, x_opt, slack, fval, (hipStream_t)stream); }
   if (e != hipSuccess) return hipfail(e, "ltv_post_launch");
+  if (timing) { e = hipEventRecord(g_evf[1], (hipStream_t)stream); if (e != hipSuccess) return hipfail(e, "hipEventRecord"); }
   return 0;
 }
 
@@ -454,8 +486,25 @@ int fsaempc_debug_set_dump(double* out, int stage) { g_dump.store(out); g_dump_s
 int fsaempc_qp_set_timing(int enable) {
   if (enable && !g_ev[0]) {
     for (int i = 0; i < 3; ++i) { hipError_t e = hipEventCreate(&g_ev[i]); if (e != hipSuccess) return hipfail(e, "hipEventCreate"); }
+    for (int i = 0; i < 2; ++i) { hipError_t e = hipEventCreate(&g_evf[i]); if (e != hipSuccess) return hipfail(e, "hipEventCreate"); }
   }
   g_timing.store(enable != 0);
+  return 0;
+}
+
+int fsaempc_ltv_get_timing(double* build_ms, double* prep_ms, double* solve_ms, double* post_ms) {
+  if (!g_evf[0]) return fail(FSAEMPC_ERR_ARG, "timing was never enabled");
+  hipError_t e = hipEventSynchronize(g_evf[1]);
+  if (e != hipSuccess) return hipfail(e, "hipEventSynchronize (no fused step since timing was enabled?)");
+  float t[4] = {0, 0, 0, 0};
+  e = hipEventElapsedTime(&t[0], g_evf[0], g_ev[0]); if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+  e = hipEventElapsedTime(&t[1], g_ev[0], g_ev[1]); if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+  e = hipEventElapsedTime(&t[2], g_ev[1], g_ev[2]); if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+  e = hipEventElapsedTime(&t[3], g_ev[2], g_evf[1]); if (e != hipSuccess) return hipfail(e, "hipEventElapsedTime");
+  if (build_ms) *build_ms = t[0];
+  if (prep_ms) *prep_ms = t[1];
+  if (solve_ms) *solve_ms = t[2];
+  if (post_ms) *post_ms = t[3];
   return 0;
 }
 

@@ -311,6 +311,12 @@ int fsaempc_debug_set_dump(double* out, int stage);
  * Process-global switch for benchmarks (bench.py); not thread-safe. */
 int fsaempc_qp_set_timing(int enable);
 int fsaempc_qp_get_timing(double* prep_ms, double* solve_ms);
+/* Same switch, for the last fsaempc_ltv_step_batch_device[_aux] call: the four phases of the fused step (construction kernel,
+ * prep = scaling / repack / launch order, interior-point solve, post-solve kernel) by HIP events on the launch stream.
+ * Every phase is also a roctx range on the calling thread (fsaempc.ltv.step > fsaempc.ltv.build, fsaempc.qp.prep+solve,
+ * fsaempc.ltv.post; `rocprofv3 --marker-trace --kernel-trace`), through librocprofiler-sdk-roctx (or roctracer's libroctx64) if the process can load it (FSAEMPC_ROCTX=0
+ * turns the ranges off). */
+int fsaempc_ltv_get_timing(double* build_ms, double* prep_ms, double* solve_ms, double* post_ms);
 
 #ifdef __cplusplus
 }

@@ -383,6 +383,33 @@ def test_full_size_config2_properties(fm, torch_, orc):
     assert torch.equal(c["x"], a["x"][sl])
 
 
+def test_fused_step_phase_timing(fm, torch_):
+    """fsaempc_ltv_get_timing: the four phases of the last fused step by HIP events on the launch stream -- each positive, together
+    no longer than the host-side wall time of the step."""
+    import time
+    torch = torch_
+    tr = fm.Track.load("fsg2019")
+    B, N = 512, 40
+    x0, xl, ul, xr = fm.instances(0, N, 0.05, tr.L, 20190, range(B))
+    st = fm.LtvBatch(0, N, 0.05, tr, B)
+    a = [_dev(torch, v) for v in (x0, xr, xl, ul)]
+    st.step(*a); torch.cuda.synchronize()
+    L = fm.lib()
+    assert L.fsaempc_qp_set_timing(1) == 0
+    try:
+        t0 = time.perf_counter()
+        st.step(*a)
+        ph = [C.c_double(-1) for _ in range(4)]
+        assert L.fsaempc_ltv_get_timing(*[C.byref(p) for p in ph]) == 0
+        wall = 1e3 * (time.perf_counter() - t0)
+    finally:
+        L.fsaempc_qp_set_timing(0)
+    ms = [p.value for p in ph]
+    assert all(v > 0 for v in ms), ms
+    assert sum(ms) <= wall * 1.05 + 0.05, (ms, wall)
+    assert ms[2] > ms[3]          # the solve outlasts the post-solve kernel
+
+
 @pytest.mark.parametrize("model,N,B", [(0, 40, 1536), (1, 60, 300)])
 def test_launch_order_is_a_stable_sort_and_changes_nothing(fm, torch_, model, N, B):
     """Batches of more than 256 instances are solved hardest-looking first (qp_solver.h QpParams::order; both solve kernels).
