@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024) void qp_prep_kernel(QpParams P) {
 // with it the timing of a batch -- is the same every run)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void qp_order_kernel(const int* __restrict__ score, int* __restrict__ order, int batch) {
-  constexpr int NBIN = 1024, NWV = 8;
+  constexpr int NBIN = 1024, NWV = 8;   // (10-bit keys: group() below)
   __shared__ int cnt[NWV][NBIN], scan[NBIN];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
   for (int e = tid; e < NWV * NBIN; e += 1024) (&cnt[0][0])[e] = 0;
@@ -370,17 +370,27 @@ __global__ __launch_bounds__(1024) void qp_order_kernel(const int* __restrict__ 
   auto bin = [&](int i) { return NBIN - 1 - min(max(score[i], 0), NBIN - 1); };   // bin 0 = highest score
   // rank of this lane among the lanes of its wavefront holding the same bin (lower lanes first), and that group's size
   auto group = [&](int k, bool on, int& rank, int& size) {
-    rank = 0; size = 0;
-    for (int l = 0; l < 64; ++l) {
-      const int kl = __shfl(on ? k : -1, l);
-      rank += (kl == k && l < lane); size += (kl == k);
+    unsigned long long same = __builtin_amdgcn_ballot_w64(on);   // lanes holding the same bin: one ballot per key bit
+#pragma unroll
+    for (int bit = 0; bit < 10; ++bit) {
+      const bool one = (k >> bit) & 1;
+      const unsigned long long v = __builtin_amdgcn_ballot_w64(one);
+      same &= one ? v : ~v;
     }
+    rank = __popcll(same & ((1ull << lane) - 1ull)); size = __popcll(same);
   };
+  // (eight rounds of ids per trip: their score loads are in flight together -- one dependent load per round made this kernel 44 us)
   if (w < NWV)
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-      const int i = i0 + lane; const bool on = i < hi; const int k = on ? bin(i) : 0;
-      int rank, size; group(k, on, rank, size);
-      if (on && rank == 0) cnt[w][k] += size;
+    for (int i0 = lo; i0 < hi; i0 += 512) {
+      int kv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const int i = i0 + 64 * r + lane; kv[r] = i < hi ? bin(i) : -1; }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bool on = kv[r] >= 0; const int k = on ? kv[r] : 0;
+        int rank, size; group(k, on, rank, size);
+        if (on && rank == 0) cnt[w][k] += size;
+      }
     }
   __syncthreads();
   int v = 0;
@@ -397,12 +407,18 @@ __global__ __launch_bounds__(1024) void qp_order_kernel(const int* __restrict__ 
   for (int ww = 0; ww < NWV; ++ww) { const int c = cnt[ww][tid]; cnt[ww][tid] = run; run += c; }
   __syncthreads();
   if (w < NWV)
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-      const int i = i0 + lane; const bool on = i < hi; const int k = on ? bin(i) : 0;
-      int rank, size; group(k, on, rank, size);
-      int base = on ? cnt[w][k] : 0;
-      if (on) order[base + rank] = i;
-      if (on && rank == 0) cnt[w][k] = base + size;   // (one writer per bin and round; read above by every lane of the group first)
+    for (int i0 = lo; i0 < hi; i0 += 512) {
+      int kv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const int i = i0 + 64 * r + lane; kv[r] = i < hi ? bin(i) : -1; }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bool on = kv[r] >= 0; const int k = on ? kv[r] : 0;
+        int rank, size; group(k, on, rank, size);
+        int base = on ? cnt[w][k] : 0;
+        if (on) order[base + rank] = i0 + 64 * r + lane;
+        if (on && rank == 0) cnt[w][k] = base + size;   // (one writer per bin and round; read above by every lane of the group first)
+      }
     }
 }
 
