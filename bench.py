@@ -196,7 +196,7 @@ def main():
     ns_ = 4 if nC == 10 * (nV - 4) else (1 if nC == 3 * (nV - 1) else 0)
     if nV >= 16 and 1 <= rem <= 4:
         Tt, NBt = nV // 16, (1 if rem == 1 else 4)
-    elif ns_ and nV >= 20 and ((nV - ns_ + 15) // 16 < (nV + 15) // 16 or (nV - ns_ + 15) // 16 >= 6):
+    elif ns_ and nV >= 20:   # (every LTV-shaped QP since the final sweeps of round 3, qp_make_dims)
         Tt, NBt = (nV - ns_ + 15) // 16, (1 if ns_ == 1 else 4)
     else:
         Tt, NBt = (nV + 15) // 16, 0

@@ -2359,15 +2359,17 @@ void qp_make_dims(int n, int m, QpDims* d) {
   // tiles and the structural sparsity of the condensed constraints is lost (dynamic N = 60: nV = 124 = 7 x 16 + 12: measured
   // 10.8 k instead of 4.6 k MFMAs per iteration in pass 1).  Shapes with the row / column signature of the reference's QPs
   // (kinematic: nC = 6N, nV = 2N + 1; dynamic: nC = 20N, nV = 2N + 4 -- ltvmpc_*.m:38-41, *_state_constraints.m) therefore keep
-  // their 1 / 4 trailing slack columns as the border whatever nV mod 16 is -- where that pays: it saves a tile row / column, or the
-  // shape is large enough (T >= 6) for the skipped operand tiles to outweigh the border's VALU work (kinematic N = 20, T = 3 either
-  // way, lost 10 % under the policy and is left alone).  A performance policy only: results do not depend on it
-  // (FSAEMPC_SLACK_BORDER=0 switches it off, =2 applies it to every LTV-shaped QP: A/B runs and tests).
+  // their 1 / 4 trailing slack columns as the border whatever nV mod 16 is.  It began as a performance policy applied only where it
+  // pays (a tile row / column saved, or T >= 6); it is applied to every such shape since the sweeps of the final round-3 build: with the
+  // zero-curvature, 1e8-cost slack column INSIDE the MFMA core the one-wavefront kernel lost kinematic N = 20 instance 15377 (a step of
+  // the end game went non-finite; ids 0..16383 all solved, vertex rate 98.7 -> 99.0 % with the column as the border; the cost measured
+  // on that shape is within noise now, 910 k vs 914 k QP/s).  FSAEMPC_SLACK_BORDER=0 switches it off, =1 is the old "where it pays"
+  // rule (A/B runs and tests).
   if (d->nb == 0 && n >= 20) {
     const char* sb = getenv("FSAEMPC_SLACK_BORDER");
     const int ns = (m == 10 * (n - 4) && ((n - 4) % 2) == 0) ? 4 : ((m == 3 * (n - 1) && ((n - 1) % 2) == 0) ? 1 : 0);
     const int Tp = (n - ns + 15) / 16;
-    const bool pays = Tp < d->T || Tp >= 6 || (sb && sb[0] == '2');
+    const bool pays = !(sb && sb[0] == '1') || Tp < d->T || Tp >= 6;
     if (ns > 0 && pays && !(sb && sb[0] == '0') && Tp <= QP_MAX_T) {
       d->T = Tp; d->nb = ns;
       d->n = 16 * d->T + ns;     // the solver's variable count: the core padded with dummy variables (qp_solver.h: QpDims::nu)

@@ -466,6 +466,11 @@ def test_regression_qps_of_earlier_misses(fm, torch_, orc):
     x0, xl, ul, xr = fm.instances(0, 40, 0.05, otr.L, 20190, [6585, 6584, 6586])
     q = orc.build_qp_batch(0, otr, 40, 0.05, x0, xr, xl, ul)
     cases = [("kin40_id6585", {k: q[k][:1] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")})]
+    # kinematic N = 20 instance 15377: -1 with a non-finite x on the one-wavefront kernel while the slack column sat inside the MFMA
+    # core (final sweeps of round 3); solved since the slack column is the border at every size (qp_make_dims)
+    x0b, xlb, ulb, xrb = fm.instances(0, 20, 0.05, otr.L, 20190, [15377])
+    qb = orc.build_qp_batch(0, otr, 20, 0.05, x0b, xrb, xlb, ulb)
+    cases.append(("kin20_id15377", {k: qb[k][:1] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")}))
     for path in regress_files():
         z = np.load(path)
         cases.append((os.path.basename(path), {k: z[k][None] for k in ("H", "g", "A", "lb", "ub", "lbA", "ubA")}))
